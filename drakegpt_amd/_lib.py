@@ -1,0 +1,94 @@
+"""ctypes binding of libdrakegpt_hip.so (include/drakegpt_hip.h).
+
+There is NO fallback: if the library is missing or a symbol cannot be bound, importing this module
+raises.  `import torch` happens first so that the HIP runtime the kernels bind to
+(DT_NEEDED libamdhip64.so.7, no rpath) is the one PyTorch-ROCm already loaded.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below: shares torch's libamdhip64)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdrakegpt_hip.so")
+
+DG_F32 = 0
+DG_BF16 = 1
+ABI_VERSION = 1
+
+
+class GemmNtArgs(C.Structure):
+    """struct dg_gemm_nt_args"""
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64),
+        ("B", C.c_void_p), ("ldb", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("in_dtype", C.c_int32), ("out_dtype", C.c_int32),
+        ("bias", C.c_void_p),
+        ("relu", C.c_int32),
+        ("relu_mask", C.c_void_p), ("ldmask", C.c_int64),
+        ("residual", C.c_void_p), ("ldr", C.c_int64),
+        ("dropout_p", C.c_float),
+        ("rng_state", C.c_void_p),
+        ("site", C.c_uint32),
+    ]
+
+
+_vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+
+# name -> argtypes; every entry of include/drakegpt_hip.h (tests/test_abi.py checks the two agree)
+SIGNATURES = {
+    "dg_version": [],
+    "dg_state_advance": [_vp, _vp],
+    "dg_batch_gather": [_vp, _i64, _vp, _vp, _vp, _i, _i, _vp],
+    "dg_embed_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "dg_embed_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "dg_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp],
+    "dg_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "dg_gemm_nt": [C.POINTER(GemmNtArgs), _vp],
+    "dg_gemm_tn": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp],
+    "dg_reduce_partials": [_vp, _i64, _i, _vp, _i64, _vp],
+    "dg_colsum": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _vp],
+    "dg_dropout_bwd_cast": [_vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp, _u32, _vp, _i64, _vp, _i64, _i, _vp],
+    "dg_cast": [_vp, _i, _vp, _i, _i64, _vp],
+    "dg_transpose_cast": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp],
+    "dg_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
+    "dg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
+    "dg_cross_entropy": [_vp, _i64, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _i, _vp],
+    "dg_reduce_sum": [_vp, _i64, _f, _vp, _vp],
+    "dg_softmax_rows": [_vp, _i64, _vp, _i64, _i, _i, _vp],
+    "dg_adamw_step": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp],
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"drakegpt_amd: {LIB_PATH} is missing. Build it with `python -m drakegpt_amd.build` "
+            "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"drakegpt_amd: {LIB_PATH} does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.dg_error_string.argtypes = [C.c_int]
+    lib.dg_error_string.restype = C.c_char_p
+    v = lib.dg_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"drakegpt_amd: ABI version mismatch: library {v}, python {ABI_VERSION}; rebuild")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib.dg_error_string(rc)
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,30 @@
+// dg_attn_fwd / dg_attn_bwd: dispatch between the generic VALU kernels (attention_simple.hip) and
+// the bf16 MFMA flash kernels (attention_mfma.hip, head size 64).
+#include "common.h"
+
+int dg_attn_fwd_simple(const void*, void*, float*, int, int, int, int, float, float, const uint32_t*, uint32_t, int, hipStream_t);
+int dg_attn_bwd_simple(const void*, const void*, const void*, const float*, void*, float*, int, int, int, int, float, float,
+                       const uint32_t*, uint32_t, int, hipStream_t);
+int dg_attn_fwd_mfma(const void*, void*, float*, int, int, int, int, float, float, const uint32_t*, uint32_t, hipStream_t);
+int dg_attn_bwd_mfma(const void*, const void*, const void*, const float*, void*, float*, int, int, int, int, float, float,
+                     const uint32_t*, uint32_t, hipStream_t);
+bool dg_attn_mfma_supported(int B, int T, int NH, int H);
+
+extern "C" int dg_attn_fwd(const void* qkv, void* out, float* lse, int B, int T, int NH, int H,
+                           float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
+                           int dtype, void* stream) {
+    if (!qkv || !out || !lse) return DG_ERR_ARG;
+    if (dtype == DG_BF16 && dg_attn_mfma_supported(B, T, NH, H))
+        return dg_attn_fwd_mfma(qkv, out, lse, B, T, NH, H, scale, dropout_p, rng_state, site, (hipStream_t)stream);
+    return dg_attn_fwd_simple(qkv, out, lse, B, T, NH, H, scale, dropout_p, rng_state, site, dtype, (hipStream_t)stream);
+}
+
+extern "C" int dg_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                           void* dqkv, float* delta_ws, int B, int T, int NH, int H,
+                           float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
+                           int dtype, void* stream) {
+    if (!qkv || !out || !dout || !lse || !dqkv || !delta_ws) return DG_ERR_ARG;
+    if (dtype == DG_BF16 && dg_attn_mfma_supported(B, T, NH, H))
+        return dg_attn_bwd_mfma(qkv, out, dout, lse, dqkv, delta_ws, B, T, NH, H, scale, dropout_p, rng_state, site, (hipStream_t)stream);
+    return dg_attn_bwd_simple(qkv, out, dout, lse, dqkv, delta_ws, B, T, NH, H, scale, dropout_p, rng_state, site, dtype, (hipStream_t)stream);
+}

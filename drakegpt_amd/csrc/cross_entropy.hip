@@ -1,0 +1,49 @@
+// Fused row-wise cross entropy forward + backward (ref: F.cross_entropy at src/model.py:604-607).
+// HBM-bound: one wave64 per row; the row is read twice from L2/HBM (max+sum pass, gradient pass).
+// Algorithmic bytes per row: V*4 read (+ V*sizeof(dlogits) written when training).
+#include "common.h"
+
+template <typename TD>
+__global__ void cross_entropy_kernel(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ targets,
+                                     float* __restrict__ loss_rows, TD* __restrict__ dlogits, int64_t ldd,
+                                     float grad_scale, const float* __restrict__ gs_dev, int M, int V) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* x = logits + (int64_t)row * ldl;
+    float mx = -INFINITY;
+    for (int i = lane; i < V; i += 64) mx = fmaxf(mx, x[i]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int i = lane; i < V; i += 64) s += expf(x[i] - mx);
+    s = wave_sum(s);
+    int64_t t = targets[row];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    const float lse = mx + logf(s);
+    if (lane == 0) loss_rows[row] = lse - x[t];
+    if (dlogits) {
+        TD* d = dlogits + (int64_t)row * ldd;
+        const float inv = 1.f / s;
+        if (gs_dev) grad_scale *= gs_dev[0];
+        for (int i = lane; i < (int)ldd; i += 64) {
+            float g = 0.f;
+            if (i < V) g = (expf(x[i] - mx) * inv - (i == (int)t ? 1.f : 0.f)) * grad_scale;
+            d[i] = from_f32<TD>(g);
+        }
+    }
+}
+
+extern "C" int dg_cross_entropy(const float* logits, int64_t ldl, const int64_t* targets, float* loss_rows,
+                                void* dlogits, int64_t ldd, int dtype, float grad_scale, const float* grad_scale_dev, int M, int V, void* stream) {
+    if (!logits || !targets || !loss_rows || M <= 0 || V <= 0 || ldl < V) return DG_ERR_ARG;
+    if (dlogits && ldd < V) return DG_ERR_ARG;
+    dim3 grid((M + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DG_BF16)
+        hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, grid, block, 0, s, logits, ldl, targets, loss_rows, (bf16_t*)dlogits, ldd, grad_scale, grad_scale_dev, M, V);
+    else if (dtype == DG_F32)
+        hipLaunchKernelGGL(cross_entropy_kernel<float>, grid, block, 0, s, logits, ldl, targets, loss_rows, (float*)dlogits, ldd, grad_scale, grad_scale_dev, M, V);
+    else return DG_ERR_DTYPE;
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}

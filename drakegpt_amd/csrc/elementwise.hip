@@ -1,0 +1,444 @@
+// HBM-bound glue kernels: batch gather, embeddings, casts, dropout-backward, column sums,
+// partial reduction, row softmax, AdamW.  All are coalesced 16-B-per-lane streams where the
+// shape allows it (cdna guide G13); none has cross-workgroup reuse, so no XCD remap (T1: null).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+__global__ void state_advance_kernel(uint32_t* st) { st[2] += 1u; }
+
+extern "C" int dg_state_advance(uint32_t* rng_state, void* stream) {
+    if (!rng_state) return DG_ERR_ARG;
+    hipLaunchKernelGGL(state_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// get_batch (ref: src/preprocessing.py:43-45)
+__global__ void batch_gather_kernel(const int64_t* __restrict__ corpus, int64_t n_corpus,
+                                    const int64_t* __restrict__ off, int64_t* __restrict__ x,
+                                    int64_t* __restrict__ y, int B, int T) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * T) return;
+    int b = (int)(i / T), t = (int)(i % T);
+    int64_t o = off[b] + t;
+    // offsets come from randint(n - T): o + 1 <= n - 1.  Clamp anyway: never fault on bad input.
+    int64_t o1 = o + 1;
+    if (o < 0) o = 0; if (o >= n_corpus) o = n_corpus - 1;
+    if (o1 < 0) o1 = 0; if (o1 >= n_corpus) o1 = n_corpus - 1;
+    x[i] = corpus[o];
+    y[i] = corpus[o1];
+}
+
+extern "C" int dg_batch_gather(const int64_t* corpus, int64_t n_corpus, const int64_t* offsets,
+                               int64_t* x, int64_t* y, int B, int T, void* stream) {
+    if (!corpus || !offsets || !x || !y || B <= 0 || T <= 0 || n_corpus < 2) return DG_ERR_ARG;
+    int64_t n = (int64_t)B * T;
+    hipLaunchKernelGGL(batch_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, corpus, n_corpus, offsets, x, y, B, T);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// embeddings (ref: src/model.py:595-597)
+template <int VEC>
+__global__ void embed_fwd_kernel(const int64_t* __restrict__ idx, const float* __restrict__ tok,
+                                 const float* __restrict__ pos, float* __restrict__ x,
+                                 int64_t M, int T, int C, int V) {
+    const int cv = C / VEC;
+    int64_t total = M * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t m = i / cv;
+        int c = (int)(i % cv) * VEC;
+        int64_t v = idx[m];
+        v = v < 0 ? 0 : (v >= V ? V - 1 : v);
+        int t = (int)(m % T);
+        if (VEC == 4) {
+            f32x4 a = *(const f32x4*)(tok + v * C + c);
+            if (pos) a += *(const f32x4*)(pos + (int64_t)t * C + c);
+            *(f32x4*)(x + m * C + c) = a;
+        } else {
+            float a = tok[v * C + c];
+            if (pos) a += pos[(int64_t)t * C + c];
+            x[m * C + c] = a;
+        }
+    }
+}
+
+extern "C" int dg_embed_fwd(const int64_t* idx, const float* tok, const float* pos, float* x,
+                            int B, int T, int C, int V, void* stream) {
+    if (!idx || !tok || !x || B <= 0 || T <= 0 || C <= 0 || V <= 0) return DG_ERR_ARG;
+    int64_t M = (int64_t)B * T;
+    bool vec = (C % 4 == 0) && dg_aligned16(tok) && dg_aligned16(x) && (!pos || dg_aligned16(pos));
+    int64_t total = vec ? M * (C / 4) : M * C;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (vec)
+        hipLaunchKernelGGL(embed_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, tok, pos, x, M, T, C, V);
+    else
+        hipLaunchKernelGGL(embed_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, tok, pos, x, M, T, C, V);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// token table: scatter-add rows with fp32 atomics (one dword per lane, contiguous per wave:
+// the shape the atomic units like -- microarch "Global float atomics")
+__global__ void embed_bwd_tok_kernel(const int64_t* __restrict__ idx, const float* __restrict__ dx,
+                                     float* __restrict__ dtok, int64_t M, int C, int V) {
+    int64_t total = M * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t m = i / C;
+        int c = (int)(i % C);
+        int64_t v = idx[m];
+        v = v < 0 ? 0 : (v >= V ? V - 1 : v);
+        atomicAdd(dtok + v * C + c, dx[i]);
+    }
+}
+// position table: dpos[t,c] = sum_b dx[b,t,c]   (fixed order: deterministic)
+__global__ void embed_bwd_pos_kernel(const float* __restrict__ dx, float* __restrict__ dpos,
+                                     int B, int T, int C) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tc = (int64_t)T * C;
+    if (i >= tc) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dx[(int64_t)b * tc + i];
+    dpos[i] = s;
+}
+
+extern "C" int dg_embed_bwd(const int64_t* idx, const float* dx, float* dtok, float* dpos,
+                            int B, int T, int C, int V, void* stream) {
+    if (!idx || !dx || !dtok || B <= 0 || T <= 0 || C <= 0 || V <= 0) return DG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t M = (int64_t)B * T;
+    hipError_t e = hipMemsetAsync(dtok, 0, (size_t)V * C * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    int64_t total = M * C;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3(grid), dim3(256), 0, s, idx, dx, dtok, M, C, V);
+    DG_LAUNCH_CHECK();
+    if (dpos) {
+        int64_t tc = (int64_t)T * C;
+        hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, s, dx, dpos, B, T, C);
+        DG_LAUNCH_CHECK();
+    }
+    return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// casts
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, int64_t n) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = to_f32<TI>(in[i * 4 + j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[i * 4 + j] = from_f32<TO>(v[j]);
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = from_f32<TO>(to_f32<TI>(in[i]));
+}
+
+extern "C" int dg_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream) {
+    if (!in || !out || n < 0) return DG_ERR_ARG;
+    if (n == 0) return DG_OK;
+    unsigned grid = (unsigned)((n / 4 + 255) / 256);
+    if (grid == 0) grid = 1;
+    if (grid > 4096) grid = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == DG_F32 && out_dtype == DG_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, s, (const float*)in, (bf16_t*)out, n);
+    else if (in_dtype == DG_BF16 && out_dtype == DG_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)in, (float*)out, n);
+    else if (in_dtype == DG_F32 && out_dtype == DG_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)in, (float*)out, n);
+    else
+        return DG_ERR_DTYPE;
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// out[c, r] = in[r, c]; 64x64 tile through LDS (+1 pad: conflict-free column reads)
+template <typename TO>
+__global__ void transpose_cast_kernel(const float* __restrict__ in, int64_t ldi, TO* __restrict__ out,
+                                      int64_t ldo, int R, int Cc) {
+    __shared__ float tile[64][65];
+    int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 4 row-lanes
+    for (int i = ty; i < 64; i += 4) {
+        int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cc) ? in[(int64_t)r * ldi + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        int c = c0 + i, r = r0 + tx;       // out row = c, out col = r
+        if (c < Cc && r < ldo) out[(int64_t)c * ldo + r] = from_f32<TO>(tile[tx][i]);   // r >= R reads the zero fill
+    }
+}
+
+extern "C" int dg_transpose_cast(const float* in, int64_t ldi, void* out, int64_t ldo, int dtype,
+                                 int R, int Cc, void* stream) {
+    if (!in || !out || R <= 0 || Cc <= 0 || ldi < Cc || ldo < R) return DG_ERR_ARG;
+    dim3 grid((Cc + 63) / 64, (unsigned)((ldo + 63) / 64));
+    if (dtype == DG_BF16)
+        hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, in, ldi, (bf16_t*)out, ldo, R, Cc);
+    else if (dtype == DG_F32)
+        hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, in, ldi, (float*)out, ldo, R, Cc);
+    else
+        return DG_ERR_DTYPE;
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dropout backward + cast (+ column-sum partials).  Block = 64 column-lanes (4 columns each) x 4
+// row-lanes; grid = (n_partials row chunks, ceil(N/256)).
+template <typename TI, typename TO, bool DROP>
+__global__ void dropbwd_cast_kernel(const TI* __restrict__ dy, int64_t lddy, TO* __restrict__ g, int64_t ldg,
+                                    int M, int N, float inv_keep, uint32_t thr,
+                                    const uint32_t* __restrict__ rng_state, uint32_t site,
+                                    const float* __restrict__ relu_mask, int64_t ldmask,
+                                    float* __restrict__ part, int64_t part_stride, int rows_per) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.y * 256 + lane * 4;
+    const int m_begin = blockIdx.x * rows_per;
+    int m_end = m_begin + rows_per; if (m_end > M) m_end = M;
+    uint32_t key = 0;
+    if (DROP) key = dg_site_key_dev(rng_state, site);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool full = (c + 3 < N);
+    for (int m = m_begin + ty; m < m_end; m += 4) {
+        float v[4];
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = to_f32<TI>(dy[(int64_t)m * lddy + c + j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (c + j < N) ? to_f32<TI>(dy[(int64_t)m * lddy + c + j]) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (DROP) {
+                uint32_t e = (uint32_t)m * (uint32_t)N + (uint32_t)(c + j);
+                v[j] = dg_keep(key, e, thr) ? v[j] * inv_keep : 0.f;
+            }
+            if (relu_mask && c + j < N) v[j] = relu_mask[(int64_t)m * ldmask + c + j] > 0.f ? v[j] : 0.f;
+            acc[j] += v[j];
+            if (g && c + j < N) g[(int64_t)m * ldg + c + j] = from_f32<TO>(v[j]);
+        }
+    }
+    if (part) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[ty][lane * 4 + j] = acc[j];
+        __syncthreads();
+        if (ty == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int cc = lane * 4 + j;
+                float s = red[0][cc] + red[1][cc] + red[2][cc] + red[3][cc];
+                if (c + j < N) part[(int64_t)blockIdx.x * part_stride + c + j] = s;
+            }
+        }
+    }
+}
+
+static inline int rows_per_partial(int M, int n_partials) { return (M + n_partials - 1) / n_partials; }
+
+extern "C" int dg_dropout_bwd_cast(const float* dy, int64_t lddy, void* g, int64_t ldg, int dtype,
+                                   int M, int N, float p, const uint32_t* rng_state, uint32_t site,
+                                   const float* relu_mask, int64_t ldmask,
+                                   float* colsum_part, int64_t part_stride, int n_partials, void* stream) {
+    if (!dy || M <= 0 || N <= 0 || (!g && !colsum_part)) return DG_ERR_ARG;
+    if (colsum_part && n_partials <= 0) return DG_ERR_ARG;
+    if (!colsum_part) n_partials = M < 1024 ? 1 : (M / 64 > 1024 ? 1024 : M / 64);
+    int rows_per = rows_per_partial(M, n_partials);
+    bool drop = (p > 0.f) && rng_state;
+    if (p >= 1.f) return DG_ERR_ARG;
+    float inv_keep = 1.f / (1.f - p);
+    uint32_t thr = dg_drop_threshold(p);
+    dim3 grid(n_partials, (N + 255) / 256), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(TO, DROP) hipLaunchKernelGGL((dropbwd_cast_kernel<float, TO, DROP>), grid, block, 0, s, dy, lddy, (TO*)g, ldg, M, N, inv_keep, thr, rng_state, site, relu_mask, ldmask, colsum_part, part_stride, rows_per)
+    if (dtype == DG_BF16) { if (drop) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
+    else if (dtype == DG_F32) { if (drop) LAUNCH(float, true); else LAUNCH(float, false); }
+    else return DG_ERR_DTYPE;
+#undef LAUNCH
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+extern "C" int dg_colsum(const void* A, int64_t lda, int dtype, float* part, int64_t part_stride,
+                         int n_partials, int M, int N, void* stream) {
+    if (!A || !part || M <= 0 || N <= 0 || n_partials <= 0) return DG_ERR_ARG;
+    int rows_per = rows_per_partial(M, n_partials);
+    dim3 grid(n_partials, (N + 255) / 256), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DG_BF16)
+        hipLaunchKernelGGL((dropbwd_cast_kernel<bf16_t, float, false>), grid, block, 0, s, (const bf16_t*)A, lda, (float*)nullptr, (int64_t)0, M, N, 1.f, 0u, (const uint32_t*)nullptr, 0u, (const float*)nullptr, (int64_t)0, part, part_stride, rows_per);
+    else if (dtype == DG_F32)
+        hipLaunchKernelGGL((dropbwd_cast_kernel<float, float, false>), grid, block, 0, s, (const float*)A, lda, (float*)nullptr, (int64_t)0, M, N, 1.f, 0u, (const uint32_t*)nullptr, 0u, (const float*)nullptr, (int64_t)0, part, part_stride, rows_per);
+    else return DG_ERR_DTYPE;
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int64_t stride, int n_partials,
+                                       float* __restrict__ out, int64_t n, int vec_ok) {
+    int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    if (vec_ok) {
+        int64_t n4 = n / 4;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gs) {
+            f32x4 s = ((const f32x4*)part)[i];
+            for (int g = 1; g < n_partials; ++g) s += *(const f32x4*)(part + (int64_t)g * stride + i * 4);
+            ((f32x4*)out)[i] = s;
+        }
+        for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gs) {
+            float s = part[i];
+            for (int g = 1; g < n_partials; ++g) s += part[(int64_t)g * stride + i];
+            out[i] = s;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gs) {
+            float s = part[i];
+            for (int g = 1; g < n_partials; ++g) s += part[(int64_t)g * stride + i];
+            out[i] = s;
+        }
+    }
+}
+
+extern "C" int dg_reduce_partials(const float* partials, int64_t stride, int n_partials,
+                                  float* out, int64_t n, void* stream) {
+    if (!partials || !out || n_partials <= 0 || n < 0) return DG_ERR_ARG;
+    if (n == 0) return DG_OK;
+    int vec_ok = dg_aligned16(partials) && dg_aligned16(out) && (stride % 4 == 0);
+    int64_t work = vec_ok ? (n + 3) / 4 : n;
+    unsigned grid = (unsigned)((work + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, partials, stride, n_partials, out, n, vec_ok);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[0] = scale * sum x   (one workgroup of 1024; fixed tree => deterministic)
+__global__ void reduce_sum_kernel(const float* __restrict__ x, int64_t n, float scale, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = threadIdx.x < 16 ? red[threadIdx.x] : 0.f;
+        t = wave_sum(t);
+        if (threadIdx.x == 0) out[0] = t * scale;
+    }
+}
+
+extern "C" int dg_reduce_sum(const float* x, int64_t n, float scale, float* out, void* stream) {
+    if (!x || !out || n <= 0) return DG_ERR_ARG;
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, scale, out);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row softmax, one wave per row (generate's last-row probabilities; ref: src/model.py:631)
+__global__ void softmax_rows_kernel(const float* __restrict__ logits, int64_t ldl, float* __restrict__ probs,
+                                    int64_t ldp, int M, int V) {
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* x = logits + (int64_t)row * ldl;
+    float mx = -INFINITY;
+    for (int i = lane; i < V; i += 64) mx = fmaxf(mx, x[i]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int i = lane; i < V; i += 64) s += expf(x[i] - mx);
+    s = wave_sum(s);
+    float inv = 1.f / s;
+    for (int i = lane; i < V; i += 64) probs[(int64_t)row * ldp + i] = expf(x[i] - mx) * inv;
+}
+
+extern "C" int dg_softmax_rows(const float* logits, int64_t ldl, float* probs, int64_t ldp, int M, int V, void* stream) {
+    if (!logits || !probs || M <= 0 || V <= 0) return DG_ERR_ARG;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ldl, probs, ldp, M, V);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// AdamW over a flat buffer (ref: src/train.py:121,151).  16 B/lane streams: reads p,g,m,v and
+// writes p,m,v = 28 B/param (+2 B for the bf16 shadow).
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, const float* __restrict__ hyper,
+                             const uint32_t* __restrict__ rng_state, float grad_scale,
+                             bf16_t* __restrict__ shadow) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+    const float t = (float)(rng_state[2] + 1u);
+    const float bc1 = 1.f - powf(b1, t);
+    const float bc2 = 1.f - powf(b2, t);
+    const float step_size = lr / bc1;
+    const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+    const float decay = 1.f - lr * wd;
+    int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gs) {
+        f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gj = gg[j] * grad_scale;
+            float pj = pp[j] * decay;
+            float mj = mm[j] + (gj - mm[j]) * (1.f - b1);          // lerp, as torch does
+            float vj = vv[j] * b2 + (1.f - b2) * gj * gj;
+            float denom = sqrtf(vj) * inv_sqrt_bc2 + eps;
+            pj -= step_size * (mj / denom);
+            pp[j] = pj; mm[j] = mj; vv[j] = vj;
+            if (shadow) shadow[i * 4 + j] = (bf16_t)pj;
+        }
+        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gs) {
+        float gj = g[i] * grad_scale;
+        float pj = p[i] * decay;
+        float mj = m[i] + (gj - m[i]) * (1.f - b1);
+        float vj = v[i] * b2 + (1.f - b2) * gj * gj;
+        float denom = sqrtf(vj) * inv_sqrt_bc2 + eps;
+        pj -= step_size * (mj / denom);
+        p[i] = pj; m[i] = mj; v[i] = vj;
+        if (shadow) shadow[i] = (bf16_t)pj;
+    }
+}
+
+extern "C" int dg_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                             const uint32_t* rng_state, float grad_scale, void* shadow_bf16, void* stream) {
+    if (!p || !g || !m || !v || !hyper || !rng_state || n <= 0) return DG_ERR_ARG;
+    if (!dg_aligned16(p) || !dg_aligned16(g) || !dg_aligned16(m) || !dg_aligned16(v)) return DG_ERR_ALIGN;
+    unsigned grid = (unsigned)((n / 4 + 255) / 256);
+    if (grid == 0) grid = 1;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper, rng_state, grad_scale, (bf16_t*)shadow_bf16);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int dg_version(void) { return DG_ABI_VERSION; }
+
+extern "C" const char* dg_error_string(int code) {
+    switch (code) {
+        case DG_OK: return "ok";
+        case DG_ERR_ARG: return "drakegpt_hip: invalid argument (null pointer, non-positive size or unsupported shape)";
+        case DG_ERR_ALIGN: return "drakegpt_hip: pointer or leading dimension not 16-byte aligned";
+        case DG_ERR_DTYPE: return "drakegpt_hip: unsupported dtype code";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "drakegpt_hip: unknown error";
+    }
+}

@@ -1,0 +1,411 @@
+// MFMA GEMMs for gfx950 (wave64): every nn.Linear forward, dX and dW of the training step.
+//
+//   dg_gemm_nt : C[M,N] = epi(A[M,K] . B[N,K]^T)  -- both operands K-contiguous, which is exactly
+//                the 16x16 MFMA A/B fragment shape (8 bf16 / 4 f32 consecutive k per lane), so
+//                fragments are single 16-byte LDS reads.  Forward Linears use B = W [out,in];
+//                dX GEMMs use B = W^T (kept as a second shadow copy, refreshed by the optimizer).
+//   dg_gemm_tn : dW[P,Q] = sum_r A[r,P] B[r,Q]    -- contraction over the strided row index; bf16
+//                fragments come from ds_read_b64_tr_b16 (hardware transpose read), f32 fragments
+//                from plain 4-byte reads.  Split over r, fp32 partial slabs (no atomics).
+//
+// Structure (both): 128x128 output tile per 256-thread workgroup, 2x2 waves of 64x64 (4x4 MFMA
+// 16x16 tiles per wave, fp32 accumulators), K step = 128 bytes per row, global -> registers ->
+// LDS staging with the next tile's loads issued before the current tile's MFMAs (cdna guide T14),
+// double-buffered LDS (one barrier per K step), XOR-swizzled LDS rows (T2), XCD-aware tile order
+// (T1).  bf16: v_mfma_f32_16x16x32_bf16; f32 (parity mode): v_mfma_f32_16x16x4_f32, which is
+// bit-exact fp32 FMA accumulation (guide section 3, "FP32-input MFMA").
+#include "common.h"
+
+#define BM 128
+#define BN 128
+
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct MmaTraits;
+template <> struct MmaTraits<bf16_t> { static constexpr int EPC = 8; };   // elements per 16-byte chunk
+template <> struct MmaTraits<float>  { static constexpr int EPC = 4; };
+
+// one 16-byte fragment pair -> accumulate a 16x16 tile
+template <typename T> __device__ __forceinline__ void mma16(const u32x4& a, const u32x4& b, f32x4& c);
+template <> __device__ __forceinline__ void mma16<bf16_t>(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(const u32x4& a, const u32x4& b, f32x4& c) {
+    // lane group g = lane>>4 holds k = 4g..4g+3 of a 16-wide k block; MFMA #j consumes element j
+    // of every group, i.e. k = 4g + j: all 16 k are covered once, same permutation for A and B.
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], c, 0, 0, 0);
+}
+
+// LDS image of a [128 rows][128 bytes] operand tile: 16-byte chunk index XORed with row&7
+// (conflict-free for ds_read_b128 by 16 rows x 4 k-chunks and for the 128-B-row ds_write_b128).
+__device__ __forceinline__ int nt_lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+struct NtParams {
+    const char* A; int64_t lda_b;      // byte strides
+    const char* B; int64_t ldb_b;
+    void* C; int64_t ldc;
+    int M, N, K;
+    const float* bias;
+    int relu;
+    const void* relu_mask; int64_t ldmask;
+    const float* residual; int64_t ldr;
+    float inv_keep; uint32_t thr; int drop;
+    const uint32_t* rng_state; uint32_t site;
+    int tiles_n, n_tiles;
+};
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
+    constexpr int EPC = MmaTraits<T>::EPC;
+    constexpr int BK = 8 * EPC;                      // elements of K per step (128 bytes)
+    __shared__ __attribute__((aligned(16))) char lds[2][2][BM * 128];   // [buf][A|B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = dg_xcd_remap(blockIdx.x, p.n_tiles);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+
+    // staging map: 4 rows x 1 chunk per thread for A and for B
+    const int ld_chunk = tid & 7, ld_row = tid >> 3;          // rows ld_row + 32*i
+    const int nk = (p.K + BK - 1) / BK;
+
+    u32x4 ra[4], rb[4];
+    auto load_tile = [&](int kt) {
+        const int k_el = kt * BK + ld_chunk * EPC;
+        const bool kok = k_el < p.K;
+        const int64_t kbyte = (int64_t)k_el * (int64_t)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = ld_row + 32 * i;
+            int gm = m0 + r, gn = n0 + r;
+            ra[i] = (kok && gm < p.M) ? *(const u32x4*)(p.A + (int64_t)gm * p.lda_b + kbyte) : (u32x4){0u, 0u, 0u, 0u};
+            rb[i] = (kok && gn < p.N) ? *(const u32x4*)(p.B + (int64_t)gn * p.ldb_b + kbyte) : (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = ld_row + 32 * i;
+            *(u32x4*)(&lds[buf][0][nt_lds_off(r, ld_chunk)]) = ra[i];
+            *(u32x4*)(&lds[buf][1][nt_lds_off(r, ld_chunk)]) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);              // in flight under the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 fa[4], fb[4];
+            const int chunk = ks * 4 + fg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *(const u32x4*)(&lds[buf][0][nt_lds_off(wm * 64 + i * 16 + fr, chunk)]);
+                fb[i] = *(const u32x4*)(&lds[buf][1][nt_lds_off(wn * 64 + i * 16 + fr, chunk)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16<T>(fa[i], fb[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+    uint32_t key = 0;
+    if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
+    TO* Cp = (TO*)p.C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + fr;
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + fg * 4 + r;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.relu_mask) {
+                    float mk = to_f32<T>(((const T*)p.relu_mask)[(int64_t)row * p.ldmask + col]);
+                    v = mk > 0.f ? v : 0.f;
+                }
+                if (p.drop) {
+                    uint32_t e = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+                    v = dg_keep(key, e, p.thr) ? v * p.inv_keep : 0.f;
+                }
+                if (p.residual) v += p.residual[(int64_t)row * p.ldr + col];
+                Cp[(int64_t)row * p.ldc + col] = from_f32<TO>(v);
+            }
+        }
+    }
+}
+
+extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
+    if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return DG_ERR_ARG;
+    const int esz = a->in_dtype == DG_BF16 ? 2 : 4;
+    const int epc = 16 / esz;
+    if (a->in_dtype != DG_BF16 && a->in_dtype != DG_F32) return DG_ERR_DTYPE;
+    if (a->out_dtype != DG_BF16 && a->out_dtype != DG_F32) return DG_ERR_DTYPE;
+    if (a->in_dtype == DG_F32 && a->out_dtype == DG_BF16) return DG_ERR_DTYPE;
+    if (a->K % epc || a->lda % epc || a->ldb % epc || !dg_aligned16(a->A) || !dg_aligned16(a->B)) return DG_ERR_ALIGN;
+    if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N) return DG_ERR_ARG;
+    if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return DG_ERR_ARG;
+    NtParams p;
+    p.A = (const char*)a->A; p.lda_b = a->lda * esz;
+    p.B = (const char*)a->B; p.ldb_b = a->ldb * esz;
+    p.C = a->C; p.ldc = a->ldc;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.bias = a->bias; p.relu = a->relu;
+    p.relu_mask = a->relu_mask; p.ldmask = a->ldmask;
+    p.residual = a->residual; p.ldr = a->ldr;
+    p.drop = (a->dropout_p > 0.f && a->rng_state) ? 1 : 0;
+    p.inv_keep = 1.f / (1.f - a->dropout_p);
+    p.thr = dg_drop_threshold(a->dropout_p);
+    p.rng_state = a->rng_state; p.site = a->site;
+    const int tiles_m = (a->M + BM - 1) / BM;
+    p.tiles_n = (a->N + BN - 1) / BN;
+    p.n_tiles = tiles_m * p.tiles_n;
+    dim3 grid(p.n_tiles), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (a->in_dtype == DG_BF16 && a->out_dtype == DG_BF16)
+        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, block, 0, s, p);
+    else if (a->in_dtype == DG_BF16)
+        hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, block, 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, block, 0, s, p);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// =============================================================================================
+// TN: out[P,Q] = sum_r A[r,P] * B[r,Q]
+struct TnParams {
+    const char* A; int64_t lda_b;
+    const char* B; int64_t ldb_b;
+    float* out; int64_t ldo; int64_t split_stride;
+    int R, P, Q;
+    int tiles_q, n_tiles;
+    int r_per_split;
+};
+
+// ---- bf16: [64 r][128 cols] tiles, 256-byte rows, dual-use image (b) of the guide (T10):
+//      off(row, ch) = 256*row + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3))),  ch = 16-byte chunk 0..15
+__device__ __forceinline__ int tn_off_bf16(int row, int ch) {
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+// A 16(cols) x 8(r) fragment for the 16x16x32 MFMA, lane group g = lane>>4 supplying k = 8g..8g+7:
+// two transposed reads of 4(r) x 16(cols) blocks.  col0 is a multiple of 16.
+__device__ __forceinline__ u32x4 tn_frag_bf16(const char* tile, int r0, int col0, int lane) {
+    const int i = lane & 15, q = i >> 2, pp = i & 3;
+    const int c0 = col0 >> 3;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const char* a0 = tile + tn_off_bf16(r0 + q, c0 + (pp >> 1)) + 8 * (pp & 1);
+    const char* a1 = tile + tn_off_bf16(r0 + 4 + q, c0 + (pp >> 1)) + 8 * (pp & 1);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a1);
+    bf16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(u32x4, v);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnParams p) {
+    constexpr int BR = 64;
+    __shared__ __attribute__((aligned(16))) char lds[2][2][BR * 256];      // 64 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wq = wave & 1;
+    const int tile = dg_xcd_remap(blockIdx.x, p.n_tiles);
+    const int p0 = (tile / p.tiles_q) * 128, q0 = (tile % p.tiles_q) * 128;
+    const int split = blockIdx.y;
+    const int r_begin = split * p.r_per_split;
+    int r_end = r_begin + p.r_per_split; if (r_end > p.R) r_end = p.R;
+    const int nk = r_end > r_begin ? (r_end - r_begin + BR - 1) / BR : 0;
+
+    const int ld_ch = tid & 15, ld_row = tid >> 4;          // rows ld_row + 16*i, i < 4
+    const bool a_ok = (p0 + ld_ch * 8) < p.P, b_ok = (q0 + ld_ch * 8) < p.Q;
+    u32x4 ra[4], rb[4];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = r_begin + kt * BR + ld_row + 16 * i;
+            bool rok = r < r_end;
+            ra[i] = (rok && a_ok) ? *(const u32x4*)(p.A + (int64_t)r * p.lda_b + (int64_t)(p0 + ld_ch * 8) * 2) : (u32x4){0u, 0u, 0u, 0u};
+            rb[i] = (rok && b_ok) ? *(const u32x4*)(p.B + (int64_t)r * p.ldb_b + (int64_t)(q0 + ld_ch * 8) * 2) : (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = ld_row + 16 * i;
+            *(u32x4*)(&lds[buf][0][tn_off_bf16(r, ld_ch)]) = ra[i];
+            *(u32x4*)(&lds[buf][1][tn_off_bf16(r, ld_ch)]) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) { load_tile(0); store_tile(0); }
+    __syncthreads();
+    const int fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 fa[4], fb[4];
+            const int r0 = ks * 32 + fg * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = tn_frag_bf16(&lds[buf][0][0], r0, wp * 64 + i * 16, lane);
+                fb[i] = tn_frag_bf16(&lds[buf][1][0], r0, wq * 64 + i * 16, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16<bf16_t>(fa[i], fb[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = p.out + (int64_t)split * p.split_stride;
+    const int fr = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = q0 + wq * 64 + j * 16 + fr;
+        if (col >= p.Q) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = p0 + wp * 64 + i * 16 + fg * 4 + r;
+                if (row < p.P) out[(int64_t)row * p.ldo + col] = acc[i][j][r];
+            }
+    }
+}
+
+// ---- f32: [32 r][128 cols] tiles with 144-float row pitch (pad 16 floats: rows r, r+1 of one
+//      ds_read_b32 half-wave land on different banks)
+#define TNF_PITCH 144
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(TnParams p) {
+    constexpr int BR = 32;
+    __shared__ __attribute__((aligned(16))) float lds[2][2][BR * TNF_PITCH];     // 73.7 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wq = wave & 1;
+    const int tile = dg_xcd_remap(blockIdx.x, p.n_tiles);
+    const int p0 = (tile / p.tiles_q) * 128, q0 = (tile % p.tiles_q) * 128;
+    const int split = blockIdx.y;
+    const int r_begin = split * p.r_per_split;
+    int r_end = r_begin + p.r_per_split; if (r_end > p.R) r_end = p.R;
+    const int nk = r_end > r_begin ? (r_end - r_begin + BR - 1) / BR : 0;
+
+    const int ld_ch = tid & 31, ld_row = tid >> 5;          // rows ld_row + 8*i, i < 4
+    const bool a_ok = (p0 + ld_ch * 4) < p.P, b_ok = (q0 + ld_ch * 4) < p.Q;
+    u32x4 ra[4], rb[4];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = r_begin + kt * BR + ld_row + 8 * i;
+            bool rok = r < r_end;
+            ra[i] = (rok && a_ok) ? *(const u32x4*)(p.A + (int64_t)r * p.lda_b + (int64_t)(p0 + ld_ch * 4) * 4) : (u32x4){0u, 0u, 0u, 0u};
+            rb[i] = (rok && b_ok) ? *(const u32x4*)(p.B + (int64_t)r * p.ldb_b + (int64_t)(q0 + ld_ch * 4) * 4) : (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = ld_row + 8 * i;
+            *(u32x4*)(&lds[buf][0][r * TNF_PITCH + ld_ch * 4]) = ra[i];
+            *(u32x4*)(&lds[buf][1][r * TNF_PITCH + ld_ch * 4]) = rb[i];
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) { load_tile(0); store_tile(0); }
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < BR / 4; ++ks) {
+            float fa[4], fb[4];
+            const int r = ks * 4 + fg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = lds[buf][0][r * TNF_PITCH + wp * 64 + i * 16 + fr];
+                fb[i] = lds[buf][1][r * TNF_PITCH + wq * 64 + i * 16 + fr];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = p.out + (int64_t)split * p.split_stride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = q0 + wq * 64 + j * 16 + fr;
+        if (col >= p.Q) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = p0 + wp * 64 + i * 16 + fg * 4 + r;
+                if (row < p.P) out[(int64_t)row * p.ldo + col] = acc[i][j][r];
+            }
+    }
+}
+
+extern "C" int dg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb,
+                          float* out, int64_t ldo, int64_t split_stride, int n_splits,
+                          int R, int P, int Q, int dtype, void* stream) {
+    if (!A || !B || !out || R <= 0 || P <= 0 || Q <= 0 || n_splits <= 0) return DG_ERR_ARG;
+    if (dtype != DG_BF16 && dtype != DG_F32) return DG_ERR_DTYPE;
+    const int esz = dtype == DG_BF16 ? 2 : 4, epc = 16 / esz;
+    if (lda % epc || ldb % epc || !dg_aligned16(A) || !dg_aligned16(B)) return DG_ERR_ALIGN;
+    if (lda < P || ldb < Q || ldo < Q) return DG_ERR_ARG;
+    if (((P + epc - 1) / epc) * epc > lda || ((Q + epc - 1) / epc) * epc > ldb) return DG_ERR_ARG;
+    if (n_splits > 1 && split_stride < (int64_t)(P - 1) * ldo + Q) return DG_ERR_ARG;
+    TnParams p;
+    p.A = (const char*)A; p.lda_b = lda * esz;
+    p.B = (const char*)B; p.ldb_b = ldb * esz;
+    p.out = out; p.ldo = ldo; p.split_stride = split_stride;
+    p.R = R; p.P = P; p.Q = Q;
+    const int tiles_p = (P + 127) / 128;
+    p.tiles_q = (Q + 127) / 128;
+    p.n_tiles = tiles_p * p.tiles_q;
+    const int br = dtype == DG_BF16 ? 64 : 32;
+    int per = (R + n_splits - 1) / n_splits;
+    p.r_per_split = ((per + br - 1) / br) * br;
+    dim3 grid(p.n_tiles, n_splits), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DG_BF16) hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, block, 0, s, p);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}

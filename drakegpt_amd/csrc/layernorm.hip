@@ -1,0 +1,219 @@
+// LayerNorm forward / backward (ref: nn.LayerNorm(C) at src/model_component.py:488-489, applied
+// at :505-506).  HBM-bound: one wave64 per row, the row lives in registers (float4 per lane),
+// mean and variance by wave-shuffle reductions (no LDS, no barrier in forward).
+// Algorithmic bytes: fwd reads M*C*4 and writes M*C*sizeof(out); bwd reads 2*M*C*4 (+M*C*4 for
+// the residual gradient) and writes M*C*4.
+#include "common.h"
+
+// LN_MAXV (template): float4 per lane kept in registers; C <= 256*LN_MAXV on the fast path
+#define LN_MAXV_CAP 8
+
+template <typename TO, bool VEC, int LN_MAXV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, TO* __restrict__ y,
+                              float* __restrict__ mean, float* __restrict__ rstd, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (int64_t)row * C;
+    TO* yr = y + (int64_t)row * C;
+    const float invC = 1.f / (float)C;
+    if (VEC) {
+        const int nv = C >> 2;            // float4 count
+        f32x4 v[LN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            int i = lane + k * 64;
+            if (i < nv) { v[k] = ((const f32x4*)xr)[i]; s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]); }
+        }
+        const float mu = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            int i = lane + k * 64;
+            if (i < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { float d = v[k][j] - mu; q += d * d; }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) * invC + eps);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            int i = lane + k * 64;
+            if (i < nv) {
+                f32x4 g = ((const f32x4*)gamma)[i], b = ((const f32x4*)beta)[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) yr[i * 4 + j] = from_f32<TO>((v[k][j] - mu) * rs * g[j] + b[j]);
+            }
+        }
+    } else {
+        float s = 0.f;
+        for (int i = lane; i < C; i += 64) s += xr[i];
+        const float mu = wave_sum(s) * invC;
+        float q = 0.f;
+        for (int i = lane; i < C; i += 64) { float d = xr[i] - mu; q += d * d; }
+        const float rs = rsqrtf(wave_sum(q) * invC + eps);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        for (int i = lane; i < C; i += 64) yr[i] = from_f32<TO>((xr[i] - mu) * rs * gamma[i] + beta[i]);
+    }
+}
+
+extern "C" int dg_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
+                                float* mean, float* rstd, int M, int C, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || C <= 0) return DG_ERR_ARG;
+    bool vec = (C % 4 == 0) && (C <= 64 * 4 * LN_MAXV_CAP) && dg_aligned16(x) && dg_aligned16(gamma) && dg_aligned16(beta);
+    const int nk = (C / 4 + 63) / 64;      // float4 per lane
+    dim3 grid((M + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(TO, V, K) hipLaunchKernelGGL((ln_fwd_kernel<TO, V, K>), grid, block, 0, s, x, gamma, beta, (TO*)y, mean, rstd, M, C, eps)
+#define LAUNCH_K(TO) do { if (!vec) LAUNCH(TO, false, 1); else if (nk <= 1) LAUNCH(TO, true, 1); else if (nk == 2) LAUNCH(TO, true, 2); \
+        else if (nk == 3) LAUNCH(TO, true, 3); else if (nk == 4) LAUNCH(TO, true, 4); else LAUNCH(TO, true, 8); } while (0)
+    if (y_dtype == DG_BF16) LAUNCH_K(bf16_t);
+    else if (y_dtype == DG_F32) LAUNCH_K(float);
+    else return DG_ERR_DTYPE;
+#undef LAUNCH_K
+#undef LAUNCH
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward.  Each workgroup (4 waves) owns a contiguous chunk of rows; wave w takes rows
+// chunk_begin + w, +4, ...  Per row:  g = dy*gamma, xhat = (x-mu)*rstd,
+//   dx = rstd * (g - mean(g) - xhat*mean(g*xhat)) (+ dresid).
+// dgamma/dbeta column partials accumulate in registers per lane, are combined across the 4 waves
+// through LDS and written as partial #blockIdx.x.
+template <bool VEC, int LN_MAXV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                              const float* __restrict__ rstd, const float* __restrict__ dresid,
+                              float* __restrict__ dx, float* __restrict__ dgamma_part,
+                              float* __restrict__ dbeta_part, int64_t part_stride,
+                              int M, int C, int rows_per) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][4][C] when VEC, else unused layout below
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m_begin = blockIdx.x * rows_per;
+    int m_end = m_begin + rows_per; if (m_end > M) m_end = M;
+    const float invC = 1.f / (float)C;
+    if (VEC) {
+        const int nv = C >> 2;
+        f32x4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV];
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            int i = lane + k * 64;
+            gam[k] = (i < nv) ? ((const f32x4*)gamma)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            dg[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            db[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int row = m_begin + w; row < m_end; row += 4) {
+            const float mu = mean[row], rs = rstd[row];
+            const f32x4* dyr = (const f32x4*)(dy + (int64_t)row * C);
+            const f32x4* xr = (const f32x4*)(x + (int64_t)row * C);
+            f32x4 gv[LN_MAXV], xh[LN_MAXV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < LN_MAXV; ++k) {
+                int i = lane + k * 64;
+                if (i < nv) {
+                    f32x4 d = dyr[i], xx = xr[i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float h = (xx[j] - mu) * rs;
+                        float gg = d[j] * gam[k][j];
+                        xh[k][j] = h; gv[k][j] = gg;
+                        s1 += gg; s2 += gg * h;
+                        dg[k][j] += d[j] * h;
+                        db[k][j] += d[j];
+                    }
+                }
+            }
+            const float c1 = wave_sum(s1) * invC, c2 = wave_sum(s2) * invC;
+            f32x4* dxr = (f32x4*)(dx + (int64_t)row * C);
+            const f32x4* drr = dresid ? (const f32x4*)(dresid + (int64_t)row * C) : nullptr;
+#pragma unroll
+            for (int k = 0; k < LN_MAXV; ++k) {
+                int i = lane + k * 64;
+                if (i < nv) {
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = rs * (gv[k][j] - c1 - xh[k][j] * c2);
+                    if (drr) o += drr[i];
+                    dxr[i] = o;
+                }
+            }
+        }
+        // combine the 4 waves' column partials
+        float* lg = lds;               // [4][C]
+        float* lb = lds + 4 * C;       // [4][C]
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            int i = lane + k * 64;
+            if (i < nv) { *(f32x4*)(lg + w * C + i * 4) = dg[k]; *(f32x4*)(lb + w * C + i * 4) = db[k]; }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float a = (lg[c] + lg[C + c]) + (lg[2 * C + c] + lg[3 * C + c]);
+            float b = (lb[c] + lb[C + c]) + (lb[2 * C + c] + lb[3 * C + c]);
+            dgamma_part[(int64_t)blockIdx.x * part_stride + c] = a;
+            dbeta_part[(int64_t)blockIdx.x * part_stride + c] = b;
+        }
+    } else {
+        // generic path: any C; column partials accumulate directly in LDS [2][4][C] per wave
+        float* lg = lds; float* lb = lds + 4 * C;
+        for (int c = lane; c < C; c += 64) { lg[w * C + c] = 0.f; lb[w * C + c] = 0.f; }
+        for (int row = m_begin + w; row < m_end; row += 4) {
+            const float mu = mean[row], rs = rstd[row];
+            const float* dyr = dy + (int64_t)row * C;
+            const float* xr = x + (int64_t)row * C;
+            float s1 = 0.f, s2 = 0.f;
+            for (int c = lane; c < C; c += 64) {
+                float h = (xr[c] - mu) * rs, gg = dyr[c] * gamma[c];
+                s1 += gg; s2 += gg * h;
+                lg[w * C + c] += dyr[c] * h;
+                lb[w * C + c] += dyr[c];
+            }
+            const float c1 = wave_sum(s1) * invC, c2 = wave_sum(s2) * invC;
+            for (int c = lane; c < C; c += 64) {
+                float h = (xr[c] - mu) * rs, gg = dyr[c] * gamma[c];
+                float o = rs * (gg - c1 - h * c2);
+                if (dresid) o += dresid[(int64_t)row * C + c];
+                dx[(int64_t)row * C + c] = o;
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float a = (lg[c] + lg[C + c]) + (lg[2 * C + c] + lg[3 * C + c]);
+            float b = (lb[c] + lb[C + c]) + (lb[2 * C + c] + lb[3 * C + c]);
+            dgamma_part[(int64_t)blockIdx.x * part_stride + c] = a;
+            dbeta_part[(int64_t)blockIdx.x * part_stride + c] = b;
+        }
+    }
+}
+
+extern "C" int dg_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                const float* rstd, const float* dresid, float* dx,
+                                float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
+                                int M, int C, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma_part || !dbeta_part) return DG_ERR_ARG;
+    if (M <= 0 || C <= 0 || n_partials <= 0 || part_stride < C) return DG_ERR_ARG;
+    size_t lds_bytes = (size_t)8 * C * sizeof(float);
+    bool vec = (C % 4 == 0) && (C <= 64 * 4 * LN_MAXV_CAP) && dg_aligned16(dy) && dg_aligned16(x) && dg_aligned16(gamma) &&
+               dg_aligned16(dx) && (!dresid || dg_aligned16(dresid));
+    int rows_per = (M + n_partials - 1) / n_partials;
+    dim3 grid(n_partials), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (lds_bytes > 64 * 1024) return DG_ERR_ARG;   // C <= 2048 on either path
+    const int nk = (C / 4 + 63) / 64;
+#define LAUNCH(V, K) hipLaunchKernelGGL((ln_bwd_kernel<V, K>), grid, block, lds_bytes, s, dy, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part, part_stride, M, C, rows_per)
+    if (!vec) LAUNCH(false, 1);
+    else if (nk <= 1) LAUNCH(true, 1);
+    else if (nk == 2) LAUNCH(true, 2);
+    else if (nk == 3) LAUNCH(true, 3);
+    else if (nk == 4) LAUNCH(true, 4);
+    else LAUNCH(true, 8);
+#undef LAUNCH
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}

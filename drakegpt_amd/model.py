@@ -1,0 +1,201 @@
+"""The six DrakeGPT language models on the gfx950 HIP kernels.
+
+Mirror of the reference's src/model.py: same class names, constructor signatures, attribute and
+state_dict layout, ``forward(idx, targets=None) -> (logits, loss)`` (logits flattened to (B*T, V)
+when targets are given, src/model.py:601-609) and ``generate(idx, max_new_tokens)``.
+
+Reference quirks kept on purpose:
+  * TransformerLM owns ``ln_f`` but never applies it (src/model.py:572,598-599): the parameters
+    exist in the state_dict, take no part in compute and never receive a gradient;
+  * MultiHeadAttentionLM's per-head size is head_size // num_heads (src/model.py:264);
+  * generate() re-runs the full forward per token without a KV cache and crops to context_length
+    (src/model.py:625); sampling draws from torch's CPU generator so that, given matching logits,
+    the sampled indices are bit-identical to the reference run on CPU.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import functional as HF
+from . import ops
+from .model_component import (Block, Head, HipModule, MultiHeadAttention, ResidualBlock, ResidualBlock2)
+
+
+def model_params(params: dict, model_type: str, vocab_size: int) -> int:
+    """The reference's parameter-count ESTIMATE (src/model.py:8-63), reproduced because train.py
+    prints it (src/train.py:112-113).  It is not the true count; use
+    ``sum(p.numel() for p in model.parameters())`` for that."""
+    C, T, L = params["embedding_dim"], params["context_length"], params["num_layers"]
+    kqv = 3 * C * C
+    attention = C + kqv + C * C
+    ffw = C * 4 * C
+    mlp = C + 2 * ffw
+    total = C * vocab_size
+    if model_type != "BigramLM":
+        total += C * T + kqv + C * vocab_size
+    if model_type in ("SingleHeadAttentionLM", "MultiHeadAttentionLM"):
+        total += C * T + C * vocab_size
+    if model_type == "BlocksLM":
+        total += (kqv + ffw) * L
+    if model_type == "ResidualBlocksLM":
+        total += (kqv + 2 * ffw) * L
+    if model_type == "TransformerLM":
+        total += (attention + mlp) * L + vocab_size
+    return total
+
+
+class _LM(HipModule):
+    """forward/generate scaffolding shared by the five position-aware models."""
+
+    context_length: Optional[int]
+
+    def _embed(self, idx):
+        return HF.embed(idx, self.token_embedding_table.weight, self.position_embedding_table.weight)
+
+    def _body(self, x, rng):          # overridden
+        raise NotImplementedError
+
+    def _any_dropout(self) -> bool:
+        return False
+
+    def _head(self, x):
+        return HF.linear(x, self.lm_head.weight, self.lm_head.bias, self.act_dtype)
+
+    def forward(self, idx, targets=None):
+        if idx.dim() != 2:
+            raise ValueError("idx must be (B, T)")
+        rng = self._rng_snapshot(idx.device, self._any_dropout())
+        logits = self._head(self._body(self._embed(idx), rng))
+        if targets is None:
+            return logits, None
+        B, T, V = logits.shape
+        logits = logits.view(B * T, V)
+        loss = HF.cross_entropy(logits, targets.reshape(B * T))
+        return logits, loss
+
+    @torch.no_grad()
+    def _last_probs(self, idx):
+        logits, _ = self(idx)
+        return ops.softmax_rows(logits[:, -1, :])
+
+    def generate(self, idx, max_new_tokens, generator: Optional[torch.Generator] = None):
+        """ref: src/model.py:611-636.  softmax runs on the GPU; torch.multinomial runs on the host CPU
+        generator (the global one unless `generator` is given), as it does in the reference on CPU."""
+        for _ in range(max_new_tokens):
+            cond = idx if self.context_length is None else idx[:, -self.context_length:]
+            probs = self._last_probs(cond.contiguous())
+            nxt = torch.multinomial(probs.cpu(), num_samples=1, generator=generator)
+            idx = torch.cat((idx, nxt.to(idx.device)), dim=1)
+        return idx
+
+
+class BigramLM(_LM):
+    """ref: src/model.py:65-130: logits are a (V,V) table lookup."""
+
+    def __init__(self, vocab_size, *, precision: str = "fp32"):
+        super().__init__(precision)
+        self.context_length = None
+        self.token_embedding_table = nn.Embedding(vocab_size, vocab_size)
+
+    def forward(self, idx, targets=None):
+        logits = HF.embed(idx, self.token_embedding_table.weight, None)
+        if targets is None:
+            return logits, None
+        B, T, V = logits.shape
+        logits = logits.view(B * T, V)
+        return logits, HF.cross_entropy(logits, targets.reshape(B * T))
+
+
+class SingleHeadAttentionLM(_LM):
+    """ref: src/model.py:133-227."""
+
+    def __init__(self, vocab_size, embedding_dim, context_length, head_size, *, precision: str = "fp32"):
+        super().__init__(precision)
+        self.context_length = context_length
+        self.token_embedding_table = nn.Embedding(vocab_size, embedding_dim)
+        self.position_embedding_table = nn.Embedding(context_length, embedding_dim)
+        self.sa_head = Head(head_size, embedding_dim, context_length, precision=precision)
+        self.lm_head = nn.Linear(embedding_dim, vocab_size)
+
+    def _body(self, x, rng):
+        return self.sa_head(x)
+
+
+class MultiHeadAttentionLM(_LM):
+    """ref: src/model.py:230-331."""
+
+    def __init__(self, vocab_size, embedding_dim, context_length, head_size, num_heads, *, precision: str = "fp32"):
+        super().__init__(precision)
+        self.context_length = context_length
+        self.token_embedding_table = nn.Embedding(vocab_size, embedding_dim)
+        self.position_embedding_table = nn.Embedding(context_length, embedding_dim)
+        self.sa_head = MultiHeadAttention(num_heads, head_size // num_heads, embedding_dim, context_length, precision=precision)
+        self.lm_head = nn.Linear(embedding_dim, vocab_size)
+
+    def _body(self, x, rng):
+        return self.sa_head(x)
+
+
+class _BlocksLM(_LM):
+    def _body(self, x, rng):
+        for blk in self.blocks:
+            x = blk(x, rng)
+        return x
+
+
+class BlocksLM(_BlocksLM):
+    """ref: src/model.py:334-432."""
+
+    def __init__(self, vocab_size, embedding_dim, context_length, num_heads, num_layers, *, precision: str = "fp32"):
+        super().__init__(precision)
+        self.context_length = context_length
+        self.token_embedding_table = nn.Embedding(vocab_size, embedding_dim)
+        self.position_embedding_table = nn.Embedding(context_length, embedding_dim)
+        self.blocks = nn.Sequential(*[Block(embedding_dim, context_length, num_heads, precision=precision) for _ in range(num_layers)])
+        self.lm_head = nn.Linear(embedding_dim, vocab_size)
+
+
+class ResidualBlocksLM(_BlocksLM):
+    """ref: src/model.py:435-533."""
+
+    def __init__(self, vocab_size, embedding_dim, context_length, num_heads, num_layers, *, precision: str = "fp32"):
+        super().__init__(precision)
+        self.context_length = context_length
+        self.token_embedding_table = nn.Embedding(vocab_size, embedding_dim)
+        self.position_embedding_table = nn.Embedding(context_length, embedding_dim)
+        self.blocks = nn.Sequential(*[ResidualBlock(embedding_dim, num_heads, context_length, precision=precision) for _ in range(num_layers)])
+        self.lm_head = nn.Linear(embedding_dim, vocab_size)
+
+
+class TransformerLM(_BlocksLM):
+    """ref: src/model.py:535-636."""
+
+    def __init__(self, vocab_size, embedding_dim, context_length, num_heads, num_layers, dropout, *, precision: str = "fp32"):
+        super().__init__(precision)
+        self.context_length = context_length
+        self.token_embedding_table = nn.Embedding(vocab_size, embedding_dim)
+        self.position_embedding_table = nn.Embedding(context_length, embedding_dim)
+        self.blocks = nn.Sequential(
+            *[ResidualBlock2(embedding_dim, num_heads, context_length, dropout, precision=precision) for _ in range(num_layers)])
+        for l, blk in enumerate(self.blocks):
+            blk.set_layer_index(l)
+        self.ln_f = nn.LayerNorm(embedding_dim)      # never applied: src/model.py:598-599
+        self.lm_head = nn.Linear(embedding_dim, vocab_size)
+        self._p = float(dropout)
+
+    def _any_dropout(self) -> bool:
+        return self._p > 0.0
+
+
+MODEL_CLASSES = OrderedDict(
+    BigramLM=BigramLM,
+    SingleHeadAttentionLM=SingleHeadAttentionLM,
+    MultiHeadAttentionLM=MultiHeadAttentionLM,
+    BlocksLM=BlocksLM,
+    ResidualBlocksLM=ResidualBlocksLM,
+    TransformerLM=TransformerLM,
+)

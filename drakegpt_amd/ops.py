@@ -1,0 +1,299 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/drakegpt_hip.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the stream; every
+function extracts raw device pointers, enqueues the HIP kernel on torch's CURRENT stream and
+returns (so the calls can be captured into a hipGraph via torch.cuda.graph).  Arguments are
+validated on the host before a launch -- a kernel that faults can reset the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import DG_BF16, DG_F32, GemmNtArgs, check, lib
+
+Tensor = torch.Tensor
+
+_DT = {torch.float32: DG_F32, torch.bfloat16: DG_BF16}
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"drakegpt_amd: unsupported dtype {dtype} (float32 / bfloat16 only)") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: Tensor, name: str, dtype=None, contiguous: bool = True) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"drakegpt_amd: {name} must be a tensor on the GPU (got {getattr(t, 'device', type(t))}); "
+                           "the HIP path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"drakegpt_amd: {name} must be {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise RuntimeError(f"drakegpt_amd: {name} must be contiguous")
+
+
+def _ld(t: Tensor) -> int:
+    """leading dimension (elements) of a 2-D row-major view with unit column stride"""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError("drakegpt_amd: expected a 2-D tensor with unit column stride")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+# ------------------------------------------------------------------------------------------
+def new_rng_state(seed: int, device, step: int = 0) -> Tensor:
+    """device uint32[4] = {seed_lo, seed_hi, step, 0} (stored as int32 bit patterns)."""
+    vals = [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, step & 0xFFFFFFFF, 0]
+    vals = [v - (1 << 32) if v >= (1 << 31) else v for v in vals]
+    return torch.tensor(vals, dtype=torch.int32, device=device)
+
+
+def state_advance(rng_state: Tensor) -> None:
+    _chk(rng_state, "rng_state", torch.int32)
+    check(lib.dg_state_advance(_p(rng_state), _stream()), "dg_state_advance")
+
+
+def batch_gather(corpus: Tensor, offsets: Tensor, T: int, x: Optional[Tensor] = None, y: Optional[Tensor] = None):
+    _chk(corpus, "corpus", torch.int64)
+    _chk(offsets, "offsets", torch.int64)
+    B = offsets.numel()
+    if x is None:
+        x = torch.empty((B, T), dtype=torch.int64, device=corpus.device)
+    if y is None:
+        y = torch.empty((B, T), dtype=torch.int64, device=corpus.device)
+    check(lib.dg_batch_gather(_p(corpus), corpus.numel(), _p(offsets), _p(x), _p(y), B, T, _stream()), "dg_batch_gather")
+    return x, y
+
+
+def embed_fwd(idx: Tensor, tok: Tensor, pos: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
+    _chk(idx, "idx", torch.int64)
+    _chk(tok, "tok", torch.float32)
+    B, T = idx.shape
+    V, Cd = tok.shape
+    if pos is not None:
+        _chk(pos, "pos", torch.float32)
+        if T > pos.shape[0]:
+            raise IndexError(f"index out of range in self: sequence length {T} exceeds context_length {pos.shape[0]}")
+    if out is None:
+        out = torch.empty((B, T, Cd), dtype=torch.float32, device=idx.device)
+    check(lib.dg_embed_fwd(_p(idx), _p(tok), _p(pos), _p(out), B, T, Cd, V, _stream()), "dg_embed_fwd")
+    return out
+
+
+def embed_bwd(idx: Tensor, dx: Tensor, dtok: Tensor, dpos: Optional[Tensor]) -> None:
+    _chk(idx, "idx", torch.int64)
+    _chk(dx, "dx", torch.float32)
+    _chk(dtok, "dtok", torch.float32)
+    B, T = idx.shape
+    V, Cd = dtok.shape
+    if dpos is not None:
+        _chk(dpos, "dpos", torch.float32)
+        if dpos.shape[0] != T:
+            raise RuntimeError("dpos must be the [T, C] slice of the position gradient")
+    check(lib.dg_embed_bwd(_p(idx), _p(dx), _p(dtok), _p(dpos), B, T, Cd, V, _stream()), "dg_embed_bwd")
+
+
+def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, out_dtype: torch.dtype, eps: float = 1e-5):
+    _chk(x, "x", torch.float32)
+    _chk(gamma, "gamma", torch.float32)
+    _chk(beta, "beta", torch.float32)
+    Cd = x.shape[-1]
+    M = x.numel() // Cd
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+    check(lib.dg_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), dt_code(out_dtype), _p(mean), _p(rstd), M, Cd, eps, _stream()),
+          "dg_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dresid: Optional[Tensor],
+                  dgamma_part: Tensor, dbeta_part: Tensor, part_stride: int, n_partials: int,
+                  dx: Optional[Tensor] = None) -> Tensor:
+    _chk(dy, "dy", torch.float32)
+    _chk(x, "x", torch.float32)
+    if dresid is not None:
+        _chk(dresid, "dresid", torch.float32)
+    Cd = x.shape[-1]
+    M = x.numel() // Cd
+    if dx is None:
+        dx = torch.empty_like(x)
+    check(lib.dg_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dresid), _p(dx), _p(dgamma_part), _p(dbeta_part),
+                               part_stride, n_partials, M, Cd, _stream()), "dg_layernorm_bwd")
+    return dx
+
+
+def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] = None, K: Optional[int] = None,
+            bias: Optional[Tensor] = None, relu: bool = False, relu_mask: Optional[Tensor] = None,
+            residual: Optional[Tensor] = None, dropout_p: float = 0.0, rng_state: Optional[Tensor] = None,
+            site: int = 0, out: Optional[Tensor] = None) -> Tensor:
+    """out[M,N] = epilogue(A[M,K] @ Bm[N,K]^T).  A/Bm may carry padding columns beyond K (ld > K)."""
+    _chk(A, "A", contiguous=False)
+    _chk(Bm, "B", contiguous=False)
+    if A.dtype != Bm.dtype:
+        raise TypeError(f"gemm_nt: operand dtypes differ ({A.dtype} vs {Bm.dtype})")
+    M = A.shape[0]
+    K = A.shape[1] if K is None else K
+    N = Bm.shape[0] if N is None else N
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    a = GemmNtArgs()
+    a.A, a.lda = _p(A), _ld(A)
+    a.B, a.ldb = _p(Bm), _ld(Bm)
+    a.C, a.ldc = _p(out), _ld(out)
+    a.M, a.N, a.K = M, N, K
+    a.in_dtype, a.out_dtype = dt_code(A.dtype), dt_code(out.dtype)
+    if bias is not None:
+        _chk(bias, "bias", torch.float32)
+        if bias.numel() != N:
+            raise RuntimeError("gemm_nt: bias size mismatch")
+    a.bias = _p(bias)
+    a.relu = 1 if relu else 0
+    if relu_mask is not None:
+        _chk(relu_mask, "relu_mask", A.dtype, contiguous=False)
+        a.relu_mask, a.ldmask = _p(relu_mask), _ld(relu_mask)
+    if residual is not None:
+        _chk(residual, "residual", torch.float32, contiguous=False)
+        a.residual, a.ldr = _p(residual), _ld(residual)
+    a.dropout_p = float(dropout_p)
+    a.rng_state = _p(rng_state) if dropout_p > 0.0 else None
+    a.site = site
+    check(lib.dg_gemm_nt(C.byref(a), _stream()), "dg_gemm_nt")
+    return out
+
+
+def gemm_tn(A: Tensor, Bm: Tensor, out_part: Tensor, split_stride: int, n_splits: int, P: int, Q: int, ldo: Optional[int] = None) -> None:
+    """partials of dW[P,Q] = sum_r A[r,:P]^T B[r,:Q] into out_part (+ s*split_stride)."""
+    _chk(A, "A", contiguous=False)
+    _chk(Bm, "B", contiguous=False)
+    _chk(out_part, "out_part", torch.float32, contiguous=False)
+    if A.dtype != Bm.dtype or A.shape[0] != Bm.shape[0]:
+        raise RuntimeError("gemm_tn: operand mismatch")
+    check(lib.dg_gemm_tn(_p(A), _ld(A), _p(Bm), _ld(Bm), _p(out_part), Q if ldo is None else ldo, split_stride, n_splits,
+                         A.shape[0], P, Q, dt_code(A.dtype), _stream()), "dg_gemm_tn")
+
+
+def reduce_partials(part: Tensor, stride: int, n_partials: int, out: Tensor, n: int) -> None:
+    _chk(part, "partials", torch.float32, contiguous=False)
+    _chk(out, "out", torch.float32, contiguous=False)
+    check(lib.dg_reduce_partials(_p(part), stride, n_partials, _p(out), n, _stream()), "dg_reduce_partials")
+
+
+def colsum(A: Tensor, part: Tensor, part_stride: int, n_partials: int, N: Optional[int] = None) -> None:
+    _chk(A, "A", contiguous=False)
+    M = A.shape[0]
+    N = A.shape[1] if N is None else N
+    check(lib.dg_colsum(_p(A), _ld(A), dt_code(A.dtype), _p(part), part_stride, n_partials, M, N, _stream()), "dg_colsum")
+
+
+def dropout_bwd_cast(dy: Tensor, out_dtype: Optional[torch.dtype], p: float, rng_state: Optional[Tensor], site: int,
+                     relu_mask: Optional[Tensor] = None, colsum_part: Optional[Tensor] = None, part_stride: int = 0,
+                     n_partials: int = 0, want_g: bool = True) -> Optional[Tensor]:
+    _chk(dy, "dy", torch.float32, contiguous=False)
+    M, N = dy.shape
+    g = torch.empty((M, N), dtype=out_dtype, device=dy.device) if want_g else None
+    if relu_mask is not None:
+        _chk(relu_mask, "relu_mask", torch.float32, contiguous=False)
+    check(lib.dg_dropout_bwd_cast(_p(dy), _ld(dy), _p(g), N, dt_code(out_dtype) if want_g else DG_F32, M, N, float(p),
+                                  _p(rng_state) if p > 0.0 else None, site,
+                                  _p(relu_mask), _ld(relu_mask) if relu_mask is not None else 0,
+                                  _p(colsum_part), part_stride, n_partials, _stream()), "dg_dropout_bwd_cast")
+    return g
+
+
+def cast(x: Tensor, out_dtype: torch.dtype, out: Optional[Tensor] = None) -> Tensor:
+    _chk(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(lib.dg_cast(_p(x), dt_code(x.dtype), _p(out), dt_code(out.dtype), x.numel(), _stream()), "dg_cast")
+    return out
+
+
+def transpose_cast(W: Tensor, out_dtype: torch.dtype, ldo: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
+    """W [R,C] fp32 -> W^T [C, ldo] (ldo >= R, zero padded) in out_dtype."""
+    _chk(W, "W", torch.float32, contiguous=False)
+    R, Cc = W.shape
+    if ldo is None:
+        g = 8 if out_dtype == torch.bfloat16 else 4
+        ldo = (R + g - 1) // g * g
+    if out is None:
+        out = torch.empty((Cc, ldo), dtype=out_dtype, device=W.device)
+    check(lib.dg_transpose_cast(_p(W), _ld(W), _p(out), ldo, dt_code(out.dtype), R, Cc, _stream()), "dg_transpose_cast")
+    return out
+
+
+def attn_fwd(qkv: Tensor, B: int, T: int, NH: int, H: int, scale: float, p: float, rng_state: Optional[Tensor], site: int):
+    _chk(qkv, "qkv")
+    if qkv.shape != (B * T, 3 * NH * H):
+        raise RuntimeError(f"attn_fwd: qkv shape {tuple(qkv.shape)} != {(B * T, 3 * NH * H)}")
+    out = torch.empty((B * T, NH * H), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, NH, T), dtype=torch.float32, device=qkv.device)
+    check(lib.dg_attn_fwd(_p(qkv), _p(out), _p(lse), B, T, NH, H, float(scale), float(p), _p(rng_state) if p > 0.0 else None,
+                          site, dt_code(qkv.dtype), _stream()), "dg_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, T: int, NH: int, H: int, scale: float, p: float,
+             rng_state: Optional[Tensor], site: int) -> Tensor:
+    _chk(qkv, "qkv")
+    _chk(out, "out", qkv.dtype)
+    _chk(dout, "dout", qkv.dtype)
+    _chk(lse, "lse", torch.float32)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, NH, T), dtype=torch.float32, device=qkv.device)
+    check(lib.dg_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(delta), B, T, NH, H, float(scale), float(p),
+                          _p(rng_state) if p > 0.0 else None, site, dt_code(qkv.dtype), _stream()), "dg_attn_bwd")
+    return dqkv
+
+
+def cross_entropy(logits: Tensor, targets: Tensor, V: int, dlogits: Optional[Tensor] = None, grad_scale: float = 1.0,
+                  grad_scale_dev: Optional[Tensor] = None, loss_rows: Optional[Tensor] = None) -> Tensor:
+    _chk(logits, "logits", torch.float32, contiguous=False)
+    _chk(targets, "targets", torch.int64)
+    M = logits.shape[0]
+    if loss_rows is None:
+        loss_rows = torch.empty((M,), dtype=torch.float32, device=logits.device)
+    ldd, dcode = 0, DG_F32
+    if dlogits is not None:
+        _chk(dlogits, "dlogits", contiguous=False)
+        ldd, dcode = _ld(dlogits), dt_code(dlogits.dtype)
+    check(lib.dg_cross_entropy(_p(logits), _ld(logits), _p(targets), _p(loss_rows), _p(dlogits), ldd, dcode, float(grad_scale),
+                               _p(grad_scale_dev), M, V, _stream()), "dg_cross_entropy")
+    return loss_rows
+
+
+def reduce_sum(x: Tensor, scale: float, out: Optional[Tensor] = None) -> Tensor:
+    _chk(x, "x", torch.float32)
+    if out is None:
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+    check(lib.dg_reduce_sum(_p(x), x.numel(), float(scale), _p(out), _stream()), "dg_reduce_sum")
+    return out
+
+
+def softmax_rows(logits: Tensor) -> Tensor:
+    _chk(logits, "logits", torch.float32, contiguous=False)
+    M, V = logits.shape
+    probs = torch.empty((M, V), dtype=torch.float32, device=logits.device)
+    check(lib.dg_softmax_rows(_p(logits), _ld(logits), _p(probs), V, M, V, _stream()), "dg_softmax_rows")
+    return probs
+
+
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor, rng_state: Tensor, grad_scale: float = 1.0,
+               shadow_bf16: Optional[Tensor] = None, n: Optional[int] = None) -> None:
+    for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (hyper, "hyper")):
+        _chk(t, nm, torch.float32)
+    n = p.numel() if n is None else n
+    check(lib.dg_adamw_step(_p(p), _p(g), _p(m), _p(v), n, _p(hyper), _p(rng_state), float(grad_scale), _p(shadow_bf16), _stream()),
+          "dg_adamw_step")

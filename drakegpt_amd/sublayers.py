@@ -1,0 +1,260 @@
+"""Kernel sequences of the hot path: forward and hand-written backward of each sub-layer.
+
+Each *_fwd returns (output, saved) and each *_bwd consumes `saved`; none of them uses autograd.
+They are shared by the two callers:
+  - drakegpt_amd/functional.py wraps them in torch.autograd.Function (the drop-in nn.Module path);
+  - drakegpt_amd/engine.py runs them back to back inside one captured hipGraph (the training path).
+
+Weight gradients are emitted as partial sums through a `sink` (see GradSink below) and weight
+operands (bf16 copies / transposes) come from a `weights` provider, so that the engine can keep
+flat, persistent buffers while the autograd path allocates on the fly.
+
+Reference call sites restated here (all relative to /root/reference/):
+  attention sub-layer  x + dropout(proj(cat_h softmax(mask(q k^T * s)) v))   src/model_component.py:378-407,436-455,505
+  feed-forward         x + dropout(W2 relu(W1 ln(x) + b1) + b2)              src/model_component.py:320-325,506
+  embedding            tok[idx] + pos[arange(T)]                             src/model.py:595-597
+  lm head + CE         cross_entropy(x W^T + b, targets)                     src/model.py:599,604-607
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import ops
+
+Tensor = torch.Tensor
+
+
+def site_attn(layer: int) -> int:
+    return 4 * layer + 0
+
+
+def site_proj(layer: int) -> int:
+    return 4 * layer + 1
+
+
+def site_ffn(layer: int) -> int:
+    return 4 * layer + 2
+
+
+def granule(dtype: torch.dtype) -> int:
+    """elements per 16 bytes: the K / leading-dimension granule of the MFMA GEMMs"""
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def pad_to(n: int, g: int) -> int:
+    return (n + g - 1) // g * g
+
+
+def n_splits_for(rows: int) -> int:
+    """how many ways the dW GEMMs split their contraction over the B*T rows"""
+    return max(1, min(8, rows // 2048))
+
+
+def n_partials_for(rows: int) -> int:
+    """row-chunk partials of the column-sum style reductions (bias / LayerNorm gradients)"""
+    return max(1, min(256, rows // 32))
+
+
+# ------------------------------------------------------------------------------------------------
+class OnTheFlyWeights:
+    """Weight operands computed per call (autograd path): bf16 copy for forward, W^T for dX."""
+
+    def __init__(self, act: torch.dtype):
+        self.act = act
+
+    def fwd(self, W: Tensor) -> Tensor:
+        if self.act == torch.float32:
+            return W if W.is_contiguous() else W.contiguous()
+        return ops.cast(W.contiguous(), self.act)
+
+    def bwd(self, W: Tensor) -> Tensor:
+        return ops.transpose_cast(W, self.act)
+
+
+class LocalSink:
+    """Gradient sink of the autograd path: allocates partial buffers, reduces on `finish`."""
+
+    def __init__(self, rows: int, device):
+        self.S = n_splits_for(rows)
+        self.G = n_partials_for(rows)
+        self.device = device
+        self._pending: Dict[str, Tuple[Tensor, int, int, Tuple[int, ...]]] = {}
+        self._direct: Dict[str, Tensor] = {}
+
+    def matrix(self, key: str, P: int, Q: int):
+        part = torch.empty((self.S, P, Q), dtype=torch.float32, device=self.device)
+        self._pending[key] = (part, P * Q, self.S, (P, Q))
+        return part, P * Q, self.S
+
+    def vector(self, key: str, N: int):
+        part = torch.empty((self.G, N), dtype=torch.float32, device=self.device)
+        self._pending[key] = (part, N, self.G, (N,))
+        return part, N, self.G
+
+    def direct(self, key: str, shape) -> Tensor:
+        t = torch.zeros(shape, dtype=torch.float32, device=self.device)
+        self._direct[key] = t
+        return t
+
+    def finish(self) -> Dict[str, Tensor]:
+        out = dict(self._direct)
+        for key, (part, stride, n, shape) in self._pending.items():
+            g = torch.empty(shape, dtype=torch.float32, device=self.device)
+            ops.reduce_partials(part, stride, n, g, g.numel())
+            out[key] = g
+        return out
+
+
+@dataclass
+class Run:
+    """per-call runtime configuration"""
+    act: torch.dtype                 # GEMM operand / stored activation type
+    rng: Optional[Tensor]            # device rng state snapshot; None => no dropout (eval)
+    weights: object                  # OnTheFlyWeights | engine.ShadowWeights
+
+    def p(self, p: float) -> float:
+        return p if (self.rng is not None and p > 0.0) else 0.0
+
+
+def _as_act(run: Run, x2d: Tensor) -> Tensor:
+    return x2d if x2d.dtype == run.act else ops.cast(x2d, run.act)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention sub-layer
+def attn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor], wqkv: Tensor,
+             wproj: Optional[Tensor], bproj: Optional[Tensor], residual: bool,
+             B: int, T: int, NH: int, H: int, p_attn: float, p_proj: float, layer: int):
+    """x2d [B*T, C].  Returns y [B*T, C_out] fp32 and the tensors backward needs."""
+    if ln_w is not None:
+        h, mean, rstd = ops.layernorm_fwd(x2d, ln_w, ln_b, run.act)
+    else:
+        h, mean, rstd = _as_act(run, x2d), None, None
+    qkv = ops.gemm_nt(h, run.weights.fwd(wqkv), run.act)
+    o, lse = ops.attn_fwd(qkv, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer))
+    if wproj is not None:
+        y = ops.gemm_nt(o, run.weights.fwd(wproj), torch.float32, bias=bproj, dropout_p=run.p(p_proj),
+                        rng_state=run.rng, site=site_proj(layer), residual=x2d if residual else None)
+    else:
+        if residual:
+            raise RuntimeError("residual attention without a projection is not a reference configuration")
+        y = o if o.dtype == torch.float32 else ops.cast(o, torch.float32)
+    return y, (x2d, h, mean, rstd, qkv, o, lse)
+
+
+def attn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], wqkv: Tensor, wproj: Optional[Tensor],
+             residual: bool, B: int, T: int, NH: int, H: int, p_attn: float, p_proj: float, layer: int,
+             sink, keys: Dict[str, str], need_dx: bool = True) -> Optional[Tensor]:
+    x2d, h, mean, rstd, qkv, o, lse = saved
+    M = x2d.shape[0]
+    if wproj is not None:
+        part, stride, n = sink.vector(keys["bproj"], wproj.shape[0])
+        g = ops.dropout_bwd_cast(dy, run.act, run.p(p_proj), run.rng, site_proj(layer), colsum_part=part,
+                                 part_stride=stride, n_partials=n)
+        part, stride, n = sink.matrix(keys["wproj"], wproj.shape[0], wproj.shape[1])
+        ops.gemm_tn(g, o, part, stride, n, wproj.shape[0], wproj.shape[1])
+        do = ops.gemm_nt(g, run.weights.bwd(wproj), run.act, K=wproj.shape[0])
+    else:
+        do = _as_act(run, dy)
+    dqkv = ops.attn_bwd(qkv, o, do, lse, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer))
+    part, stride, n = sink.matrix(keys["wqkv"], wqkv.shape[0], wqkv.shape[1])
+    ops.gemm_tn(dqkv, h, part, stride, n, wqkv.shape[0], wqkv.shape[1])
+    if not need_dx:
+        return None
+    if ln_w is not None:
+        dh = ops.gemm_nt(dqkv, run.weights.bwd(wqkv), torch.float32, K=wqkv.shape[0])
+        pg, sg, ng = sink.vector(keys["ln_w"], ln_w.numel())
+        pb, _, _ = sink.vector(keys["ln_b"], ln_w.numel())
+        return ops.layernorm_bwd(dh, x2d, ln_w, mean, rstd, dy if residual else None, pg, pb, sg, ng)
+    return ops.gemm_nt(dqkv, run.weights.bwd(wqkv), torch.float32, K=wqkv.shape[0], residual=dy if residual else None)
+
+
+# ------------------------------------------------------------------------------------------------
+# feed-forward sub-layer
+def ffn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor], w1: Tensor, b1: Tensor,
+            w2: Optional[Tensor], b2: Optional[Tensor], residual: bool, p: float, layer: int):
+    if ln_w is not None:
+        h, mean, rstd = ops.layernorm_fwd(x2d, ln_w, ln_b, run.act)
+    else:
+        h, mean, rstd = _as_act(run, x2d), None, None
+    if w2 is None:
+        # FeedForward: Linear(C,C) + ReLU (ref: src/model_component.py:118-121)
+        y = ops.gemm_nt(h, run.weights.fwd(w1), torch.float32, bias=b1, relu=True)
+        return y, (x2d, h, mean, rstd, y)
+    f = ops.gemm_nt(h, run.weights.fwd(w1), run.act, bias=b1, relu=True)
+    y = ops.gemm_nt(f, run.weights.fwd(w2), torch.float32, bias=b2, dropout_p=run.p(p), rng_state=run.rng,
+                    site=site_ffn(layer), residual=x2d if residual else None)
+    return y, (x2d, h, mean, rstd, f)
+
+
+def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2: Optional[Tensor], residual: bool,
+            p: float, layer: int, sink, keys: Dict[str, str], need_dx: bool = True) -> Optional[Tensor]:
+    x2d, h, mean, rstd, f = saved
+    if w2 is None:
+        part, stride, n = sink.vector(keys["b1"], w1.shape[0])
+        df = ops.dropout_bwd_cast(dy, run.act, 0.0, None, 0, relu_mask=f, colsum_part=part, part_stride=stride, n_partials=n)
+    else:
+        part, stride, n = sink.vector(keys["b2"], w2.shape[0])
+        g = ops.dropout_bwd_cast(dy, run.act, run.p(p), run.rng, site_ffn(layer), colsum_part=part, part_stride=stride,
+                                 n_partials=n)
+        part, stride, n = sink.matrix(keys["w2"], w2.shape[0], w2.shape[1])
+        ops.gemm_tn(g, f, part, stride, n, w2.shape[0], w2.shape[1])
+        df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], relu_mask=f)
+        part, stride, n = sink.vector(keys["b1"], w1.shape[0])
+        ops.colsum(df, part, stride, n)
+    part, stride, n = sink.matrix(keys["w1"], w1.shape[0], w1.shape[1])
+    ops.gemm_tn(df, h, part, stride, n, w1.shape[0], w1.shape[1])
+    if not need_dx:
+        return None
+    if ln_w is not None:
+        dh = ops.gemm_nt(df, run.weights.bwd(w1), torch.float32, K=w1.shape[0])
+        pg, sg, ng = sink.vector(keys["ln_w"], ln_w.numel())
+        pb, _, _ = sink.vector(keys["ln_b"], ln_w.numel())
+        return ops.layernorm_bwd(dh, x2d, ln_w, mean, rstd, dy if residual else None, pg, pb, sg, ng)
+    return ops.gemm_nt(df, run.weights.bwd(w1), torch.float32, K=w1.shape[0], residual=dy if residual else None)
+
+
+# ------------------------------------------------------------------------------------------------
+# plain Linear (lm_head): y = x W^T + b, fp32 out
+def linear_fwd(run: Run, x2d: Tensor, w: Tensor, b: Optional[Tensor]):
+    xa = _as_act(run, x2d)
+    y = ops.gemm_nt(xa, run.weights.fwd(w), torch.float32, bias=b)
+    return y, (xa,)
+
+
+def linear_bwd_from_act(run: Run, saved, g: Tensor, w: Tensor, has_bias: bool, sink, keys, need_dx: bool = True,
+                        bias_done: bool = False):
+    """g: dY already in the activation dtype, leading dim padded to the granule with zeros."""
+    (xa,) = saved
+    N, K = w.shape
+    if has_bias and not bias_done:
+        part, stride, n = sink.vector(keys["b"], N)
+        ops.colsum(g, part, stride, n, N=N)
+    part, stride, n = sink.matrix(keys["w"], N, K)
+    ops.gemm_tn(g, xa, part, stride, n, N, K)
+    if not need_dx:
+        return None
+    return ops.gemm_nt(g, run.weights.bwd(w), torch.float32, K=pad_to(N, granule(run.act)))
+
+
+def linear_bwd(run: Run, saved, dy: Tensor, w: Tensor, has_bias: bool, sink, keys, need_dx: bool = True):
+    """dy fp32 [M,N] (autograd path)."""
+    N = w.shape[0]
+    gr = granule(run.act)
+    Np = pad_to(N, gr)
+    M = dy.shape[0]
+    part = stride = n = None
+    if has_bias:
+        part, stride, n = sink.vector(keys["b"], N)
+    if Np == N:
+        g = ops.dropout_bwd_cast(dy, run.act, 0.0, None, 0, colsum_part=part, part_stride=stride or 0, n_partials=n or 0)
+    else:
+        # pad the contraction dim of the dX GEMM with zeros (V = 50257 is not a multiple of 8)
+        gp = torch.zeros((M, Np), dtype=run.act, device=dy.device)
+        g = gp[:, :N]
+        ops.check(ops.lib.dg_dropout_bwd_cast(dy.data_ptr(), ops._ld(dy), gp.data_ptr(), Np, ops.dt_code(run.act), M, N, 0.0, None, 0,
+                                              None, 0, ops._p(part), stride or 0, n or 0, ops._stream()), "dg_dropout_bwd_cast")
+    return linear_bwd_from_act(run, saved, g, w, has_bias, sink, keys, need_dx, bias_done=True)

@@ -1,0 +1,192 @@
+/*
+ * drakegpt_hip.h -- C ABI of libdrakegpt_hip.so, the MI355X (gfx950) kernels behind
+ * DrakeGPT's transformer training hot path.
+ *
+ * The reference (ChrisTho23/DrakeGPT) has no native code and no FFI: every number is produced
+ * by stock ATen ops called from src/model.py and src/model_component.py (SURVEY.md section 2b
+ * lists the call sites K1..K19).  Each entry point below therefore names the reference call
+ * site(s) whose arithmetic it replaces; the Python layer in drakegpt_amd/ binds these symbols
+ * with ctypes and presents the reference's nn.Module surface on top.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host; the library allocates
+ *    nothing and owns nothing: workspaces are passed in by the caller;
+ *  - `stream` is a hipStream_t; calls only enqueue work and return immediately, so they may be
+ *    captured into a hipGraph;
+ *  - all matrices are row-major with an explicit leading dimension in ELEMENTS;
+ *  - dtype codes: DG_F32 = 0 (float), DG_BF16 = 1 (bfloat16, round-to-nearest-even);
+ *  - return value: 0 on success, a negative DG_ERR_* for a rejected argument, or a positive
+ *    hipError_t from the launch; dg_error_string() explains either;
+ *  - no global mutable state: safe to call from the autograd worker thread and the main
+ *    thread concurrently (forward runs on one, backward on the other).
+ *
+ * Dropout stream: a keep decision is a stateless hash of (seed, step, site, element index)
+ * (csrc/common.h: dg_keep).  `rng_state` points at 4 device uint32: {seed_lo, seed_hi, step, 0};
+ * the step word is advanced on the device (dg_state_advance) so a captured graph replays with
+ * fresh masks.  A NULL rng_state or p == 0 disables dropout (eval mode).
+ */
+#ifndef DRAKEGPT_HIP_H
+#define DRAKEGPT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DG_F32 0
+#define DG_BF16 1
+
+#define DG_OK 0
+#define DG_ERR_ARG (-1)       /* bad size / null pointer / unsupported combination */
+#define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
+#define DG_ERR_DTYPE (-3)
+
+#define DG_ABI_VERSION 1
+
+int dg_version(void);
+const char* dg_error_string(int code);
+
+/* {seed_lo, seed_hi, step, 0}: step += 1.  One launch of one thread. */
+int dg_state_advance(uint32_t* rng_state, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * get_batch -- ref: src/preprocessing.py:43-45.  The corpus stays resident in HBM; the B window
+ * offsets are still drawn by the host CPU generator (torch.randint) for parity and passed in.
+ * x[b, t] = corpus[off[b] + t], y[b, t] = corpus[off[b] + t + 1].  All int64. */
+int dg_batch_gather(const int64_t* corpus, int64_t n_corpus, const int64_t* offsets,
+                    int64_t* x, int64_t* y, int B, int T, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Token + position embedding -- ref: src/model.py:595-597 (K1-K3).
+ * x[b,t,:] = tok[idx[b,t],:] + pos[t,:]   (pos == NULL: BigramLM-style plain gather, :96).
+ * Returns DG_ERR_ARG if T > rows of pos is the caller's job to check; idx values are clamped
+ * to [0, V) on the device (torch would raise; the Python layer checks in debug mode). */
+int dg_embed_fwd(const int64_t* idx, const float* tok, const float* pos, float* x,
+                 int B, int T, int C, int V, void* stream);
+/* Backward of the above (embedding_dense_backward).  dtok [V,C] is zero-filled here and then
+ * accumulated with fp32 atomics; dpos [T,C] (nullable) is overwritten with sum over b. */
+int dg_embed_bwd(const int64_t* idx, const float* dx, float* dtok, float* dpos,
+                 int B, int T, int C, int V, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * LayerNorm over the last dim, eps inside the sqrt, biased variance -- ref: nn.LayerNorm at
+ * src/model_component.py:488-489 applied at :505-506 (K4).  x is the fp32 residual stream;
+ * y is written in y_dtype (the next GEMM's operand type). mean/rstd [M] are saved for bwd. */
+int dg_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
+                     float* mean, float* rstd, int M, int C, float eps, void* stream);
+/* dx = dresid (nullable, the residual branch's gradient) + LN'(dy).  dgamma/dbeta are emitted
+ * as n_partials row-chunk partial sums: partial g at dgamma_part + g*part_stride (same for
+ * dbeta_part); finish with dg_reduce_partials. */
+int dg_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                     const float* rstd, const float* dresid, float* dx,
+                     float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
+                     int M, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * GEMM "NT": C[M,N] = epilogue(A[M,K] . B[N,K]^T), MFMA with fp32 accumulation.
+ * Replaces every nn.Linear forward (y = x W^T + b; W is [out,in]) -- ref:
+ * src/model_component.py:392-393,404 (packed q/k/v), :454 (proj), :321-323 (FFN),
+ * src/model.py:599 (lm_head) -- and, with B = W^T, every Linear's dX = dY . W.
+ * Epilogue, in this order (each optional):
+ *    v = acc + bias[n];  v = max(v,0) if relu;  v = 0 where relu_mask[m,n] <= 0;
+ *    v = dropout(v; p, site);  v += residual[m,n];  C[m,n] = (out_dtype) v
+ * in_dtype: type of A, B and relu_mask.  K and lda/ldb must be multiples of 16 bytes' worth of
+ * elements (8 bf16 / 4 f32) and A, B 16-byte aligned. */
+typedef struct dg_gemm_nt_args {
+    const void* A; int64_t lda;
+    const void* B; int64_t ldb;
+    void* C; int64_t ldc;
+    int32_t M, N, K;
+    int32_t in_dtype, out_dtype;
+    const float* bias;
+    int32_t relu;
+    const void* relu_mask; int64_t ldmask;
+    const float* residual; int64_t ldr;
+    float dropout_p;
+    const uint32_t* rng_state;
+    uint32_t site;
+} dg_gemm_nt_args;
+int dg_gemm_nt(const dg_gemm_nt_args* args, void* stream);
+
+/* GEMM "TN": weight gradients, dW[P,Q] = sum_r A[r,P] * B[r,Q]  (A = dY [R,P], B = X [R,Q]).
+ * The contraction over the R = B*T rows is split n_splits ways across workgroups; split s
+ * writes its fp32 partial to out + s*split_stride (finish with dg_reduce_partials).
+ * P and Q need no alignment; lda/ldb must be multiples of 8 bf16 / 4 f32 and every 16-byte
+ * chunk that starts left of P (resp. Q) must be readable. */
+int dg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb,
+               float* out, int64_t ldo, int64_t split_stride, int n_splits,
+               int R, int P, int Q, int dtype, void* stream);
+
+/* out[i] = sum_{g < n_partials} partials[g*stride + i], i < n.  Deterministic order. */
+int dg_reduce_partials(const float* partials, int64_t stride, int n_partials,
+                       float* out, int64_t n, void* stream);
+
+/* Column sums (bias gradients): partial g (< n_partials) of sum_m A[m, n], fp32. */
+int dg_colsum(const void* A, int64_t lda, int dtype, float* part, int64_t part_stride,
+              int n_partials, int M, int N, void* stream);
+
+/* g = (dtype)(dy * keep/(1-p)) -- backward of the nn.Dropout after proj / FFN
+ * (ref: src/model_component.py:454,324); with p == 0 a plain cast.  relu_mask (nullable, fp32
+ * [M,N]): additionally g = 0 where relu_mask <= 0 (backward of the ReLU that ends FeedForward,
+ * ref: src/model_component.py:118-121).  Optionally also emits the column-sum partials of g (the
+ * bias gradient of the Linear in front). g may be NULL when only the column sums are wanted. */
+int dg_dropout_bwd_cast(const float* dy, int64_t lddy, void* g, int64_t ldg, int dtype,
+                        int M, int N, float p, const uint32_t* rng_state, uint32_t site,
+                        const float* relu_mask, int64_t ldmask,
+                        float* colsum_part, int64_t part_stride, int n_partials, void* stream);
+
+/* out = (out_dtype) in, n elements: f32 -> bf16 (shadow copies), bf16 -> f32, f32 -> f32. */
+int dg_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream);
+/* out[c, r] = (dtype) in[r, c] for r < R, c < Cc; out has leading dim ldo >= R and columns
+ * R..ldo-1 are zero-filled (W^T operands for the dX GEMMs, K padded to the MFMA granule). */
+int dg_transpose_cast(const float* in, int64_t ldi, void* out, int64_t ldo, int dtype,
+                      int R, int Cc, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Causal multi-head attention -- ref: Head2.forward src/model_component.py:392-405 for every
+ * head of MultiHeadAttention3 (:453), i.e. K5's output to K11:
+ *   S = (Q K^T) * scale; mask j > i to -inf; P = softmax(S); P = dropout(P) (no renorm); O = P V.
+ * qkv: [B*T, 3*NH*H] with column blocks [Q heads | K heads | V heads]; out: [B*T, NH*H], head h
+ * at columns h*H.. (the torch.cat of :453 disappears).  lse [B,NH,T] = log-sum-exp of the scaled
+ * masked scores, saved for backward.  Dropout element index = ((b*NH+h)*T+i)*T+j. */
+int dg_attn_fwd(const void* qkv, void* out, float* lse, int B, int T, int NH, int H,
+                float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
+                int dtype, void* stream);
+/* dqkv [B*T, 3*NH*H] from dout; delta_ws: workspace [B,NH,T] floats. */
+int dg_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                void* dqkv, float* delta_ws, int B, int T, int NH, int H,
+                float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
+                int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Cross entropy, mean over rows -- ref: F.cross_entropy at src/model.py:604-607 (K16).
+ * loss_rows[m] = logsumexp(logits[m,:]) - logits[m,target[m]].  If dlogits != NULL also writes
+ * dlogits[m,n] = (softmax(logits[m,:])[n] - [n == target]) * grad_scale (* *grad_scale_dev) in
+ * `dtype`, with columns
+ * V..ldd-1 zero-filled.  dg_reduce_mean then gives the scalar loss. */
+int dg_cross_entropy(const float* logits, int64_t ldl, const int64_t* targets, float* loss_rows,
+                     void* dlogits, int64_t ldd, int dtype, float grad_scale,
+                     const float* grad_scale_dev /* nullable: multiplies grad_scale */,
+                     int M, int V, void* stream);
+/* out[0] = scale * sum_i x[i] (single workgroup, fixed order). */
+int dg_reduce_sum(const float* x, int64_t n, float scale, float* out, void* stream);
+
+/* probs = softmax(logits) row-wise, fp32 -- ref: F.softmax at src/model.py:631 (generate). */
+int dg_softmax_rows(const float* logits, int64_t ldl, float* probs, int64_t ldp, int M, int V,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * AdamW over one flat fp32 buffer -- ref: torch.optim.AdamW(model.parameters(), lr, betas)
+ * at src/train.py:121,151 (eps 1e-8, weight_decay 1e-2 unless overridden):
+ *   p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),   t = rng_state.step + 1
+ * hyper (device): {lr, beta1, beta2, eps, weight_decay}.  grad_scale multiplies g first
+ * (1/world_size after a sum all-reduce).  Optionally refreshes a bf16 shadow copy of p. */
+int dg_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                  const uint32_t* rng_state, float grad_scale, void* shadow_bf16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRAKEGPT_HIP_H */
