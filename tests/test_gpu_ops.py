@@ -1,0 +1,284 @@
+"""Per-kernel parity: every C-ABI entry point against fp64 / oracle math on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from drakegpt_amd import ops
+    return ops
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def maxabs(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(256, 96, 32), (300, 80, 384), (1000, 1152, 384), (128, 128, 64), (2048, 384, 1536), (77, 50257 // 16, 64)])
+def test_gemm_nt_plain(dev, dtype, M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    B = torch.randn(N, K, generator=g).to(dtype)
+    ref = A.double() @ B.double().T
+    out = ops.gemm_nt(A.to(dev), B.to(dev), torch.float32)
+    torch.cuda.synchronize()
+    assert rel(out, ref) < 2e-6, rel(out, ref)
+
+
+def test_gemm_nt_asymmetric_identity(dev):
+    """A = I against an asymmetric B catches a transposed C/D map (cdna guide section 3)."""
+    ops = _ops()
+    K = 128
+    A = torch.eye(K)
+    B = torch.arange(96 * K, dtype=torch.float32).reshape(96, K) / 7.0
+    for dt in (torch.float32, torch.bfloat16):
+        out = ops.gemm_nt(A.to(dt).to(dev), B.to(dt).to(dev), torch.float32)
+        assert torch.equal(out.cpu(), B.to(dt).float().T.contiguous()), dt
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_nt_epilogue(dev, dtype):
+    from oracle import rng_ref
+    ops = _ops()
+    M, N, K = 320, 200, 128
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    B = torch.randn(N, K, generator=g).to(dtype)
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    mask = torch.randn(M, N, generator=g).to(dtype)
+    acc = A.double() @ B.double().T + bias.double()
+    # bias + relu, activation-dtype output
+    out = ops.gemm_nt(A.to(dev), B.to(dev), dtype, bias=bias.to(dev), relu=True)
+    ref = acc.clamp_min(0)
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    assert rel(out, ref) < tol
+    # relu-mask (backward of ReLU fused into the dX GEMM)
+    out = ops.gemm_nt(A.to(dev), B.to(dev), torch.float32, relu_mask=mask.to(dev))
+    ref = (A.double() @ B.double().T) * (mask.double() > 0)
+    assert rel(out, ref) < 2e-6
+    # bias + dropout + residual, fp32 out; mask recomputed on the host from the same hash
+    seed, step, site, p = 1234, 5, 9, 0.25
+    rng = ops.new_rng_state(seed, dev, step)
+    out = ops.gemm_nt(A.to(dev), B.to(dev), torch.float32, bias=bias.to(dev), dropout_p=p, rng_state=rng, site=site, residual=resid.to(dev))
+    keep = torch.from_numpy(rng_ref.keep_mask(seed, step, site, p, M * N).reshape(M, N)).double()
+    ref = acc * keep / (1 - p) + resid.double()
+    assert rel(out, ref) < 2e-6
+    frac = keep.mean().item()
+    assert abs(frac - (1 - p)) < 0.01, frac
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,P,Q,S", [(256, 96, 32, 1), (4096, 384, 384, 2), (1000, 80, 384, 3), (640, 1152, 384, 1), (16384, 128, 128, 8), (130, 200, 72, 2)])
+def test_gemm_tn(dev, dtype, R, P, Q, S):
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + P + Q)
+    A = torch.randn(R, P, generator=g).to(dtype)
+    B = torch.randn(R, Q, generator=g).to(dtype)
+    ref = A.double().T @ B.double()
+    part = torch.full((S, P, Q), float("nan"), device=dev)
+    ops.gemm_tn(A.to(dev), B.to(dev), part, P * Q, S, P, Q)
+    out = torch.empty(P, Q, device=dev)
+    ops.reduce_partials(part, P * Q, S, out, P * Q)
+    assert rel(out, ref) < 3e-6, rel(out, ref)
+
+
+def test_gemm_tn_asymmetric(dev):
+    """exact integer data through the transposed LDS reads (bf16) -- every element must match."""
+    ops = _ops()
+    R, P, Q = 128, 48, 40
+    A = ((torch.arange(R * P).reshape(R, P) % 7) - 3).float()
+    B = ((torch.arange(R * Q).reshape(R, Q) % 5) - 2).float()
+    ref = A.T @ B
+    for dt in (torch.bfloat16, torch.float32):
+        part = torch.empty((1, P, Q), device=dev)
+        ops.gemm_tn(A.to(dt).to(dev), B.to(dt).to(dev), part, P * Q, 1, P, Q)
+        assert torch.equal(part[0].cpu(), ref), dt
+
+
+@pytest.mark.parametrize("C", [32, 384, 768, 1024, 100, 2048])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_layernorm(dev, C, out_dtype):
+    ops = _ops()
+    M = 517
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(M, C, generator=g) * 2 + 0.5
+    w = torch.randn(C, generator=g)
+    b = torch.randn(C, generator=g)
+    dy = torch.randn(M, C, generator=g)
+    dres = torch.randn(M, C, generator=g)
+    xd = x.double().requires_grad_(True)
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (C,), wd, bd, 1e-5)
+    ref.backward(dy.double())
+    y, mean, rstd = ops.layernorm_fwd(x.to(dev), w.to(dev), b.to(dev), out_dtype)
+    assert rel(y, ref.detach()) < (1e-6 if out_dtype == torch.float32 else 4e-3)
+    G = 16
+    pg = torch.empty(G, C, device=dev)
+    pb = torch.empty(G, C, device=dev)
+    dx = ops.layernorm_bwd(dy.to(dev), x.to(dev), w.to(dev), mean, rstd, dres.to(dev), pg, pb, C, G)
+    assert rel(dx, xd.grad + dres.double()) < 2e-6
+    dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    ops.reduce_partials(pg, C, G, dg, C)
+    ops.reduce_partials(pb, C, G, db, C)
+    assert rel(dg, wd.grad) < 2e-6 and rel(db, bd.grad) < 2e-6
+
+
+def _attn_ref(qkv, B, T, NH, H, keep=None, p=0.0):
+    """fp64 reference of Head2.forward over packed qkv [B*T, 3*NH*H]; returns out, and is differentiable"""
+    C = NH * H
+    q, k, v = qkv.view(B, T, 3, NH, H).permute(2, 0, 3, 1, 4)          # each (B,NH,T,H)
+    w = q @ k.transpose(-2, -1) * H ** -0.5
+    tril = torch.tril(torch.ones(T, T, dtype=torch.bool))
+    w = w.masked_fill(~tril, float("-inf")).softmax(-1)
+    if keep is not None:
+        w = w * keep / (1 - p)
+    o = w @ v                                                           # (B,NH,T,H)
+    return o.permute(0, 2, 1, 3).reshape(B * T, C)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,NH,H,p", [(2, 8, 4, 8, 0.0), (3, 37, 2, 16, 0.1), (2, 256, 3, 64, 0.2), (1, 1, 1, 32, 0.0), (2, 130, 2, 64, 0.0)])
+def test_attention(dev, dtype, B, T, NH, H, p):
+    from oracle import rng_ref
+    ops = _ops()
+    g = torch.Generator().manual_seed(T * 7 + H)
+    C = NH * H
+    qkv = (torch.randn(B * T, 3 * C, generator=g)).to(dtype)
+    dout = torch.randn(B * T, C, generator=g).to(dtype)
+    seed, step, site = 77, 3, 4
+    keep = None
+    rng = None
+    if p > 0:
+        keep = torch.from_numpy(rng_ref.keep_mask(seed, step, site, p, B * NH * T * T).reshape(B, NH, T, T)).double()
+        rng = ops.new_rng_state(seed, dev, step)
+    qd = qkv.double().requires_grad_(True)
+    ref = _attn_ref(qd, B, T, NH, H, keep, p)
+    ref.backward(dout.double())
+    out, lse = ops.attn_fwd(qkv.to(dev), B, T, NH, H, H ** -0.5, p, rng, site)
+    tol = 2e-5 if dtype == torch.float32 else 8e-3
+    assert rel(out, ref.detach()) < tol, rel(out, ref.detach())
+    dqkv = ops.attn_bwd(qkv.to(dev), out, dout.to(dev), lse, B, T, NH, H, H ** -0.5, p, rng, site)
+    # backward consumes the kernel's own (rounded) forward output: compare against fp64 grads
+    tolg = 3e-5 if dtype == torch.float32 else 2e-2
+    assert rel(dqkv, qd.grad) < tolg, rel(dqkv, qd.grad)
+
+
+def test_cross_entropy_and_reduce(dev):
+    ops = _ops()
+    for M, V in ((256, 80), (64, 50257), (33, 7)):
+        g = torch.Generator().manual_seed(V)
+        logits = torch.randn(M, V, generator=g) * 3
+        tgt = torch.randint(0, V, (M,), generator=g)
+        ld = logits.double().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(ld, tgt)
+        ref.backward()
+        Vp = (V + 7) // 8 * 8
+        for dt in (torch.float32, torch.bfloat16):
+            dl = torch.full((M, Vp), float("nan"), dtype=dt, device=dev)
+            rows = ops.cross_entropy(logits.to(dev), tgt.to(dev), V, dlogits=dl, grad_scale=1.0 / M)
+            loss = ops.reduce_sum(rows, 1.0 / M)
+            assert abs(loss.item() - ref.item()) < 1e-5 * max(1, abs(ref.item()))
+            assert rel(dl[:, :V], ld.grad) < (1e-6 if dt == torch.float32 else 5e-3)
+            if Vp > V:
+                assert torch.all(dl[:, V:] == 0)
+
+
+def test_embed(dev):
+    ops = _ops()
+    B, T, C, V = 5, 8, 32, 80
+    g = torch.Generator().manual_seed(0)
+    idx = torch.randint(0, V, (B, T), generator=g)
+    tok = torch.randn(V, C, generator=g)
+    pos = torch.randn(T + 3, C, generator=g)
+    x = ops.embed_fwd(idx.to(dev), tok.to(dev), pos.to(dev))
+    assert torch.equal(x.cpu(), tok[idx] + pos[:T])
+    dx = torch.randn(B, T, C, generator=g)
+    dtok = torch.empty(V, C, device=dev)
+    dpos = torch.zeros(T + 3, C, device=dev)
+    ops.embed_bwd(idx.to(dev), dx.to(dev), dtok, dpos[:T])
+    ref_tok = torch.zeros(V, C, dtype=torch.float64).index_add_(0, idx.reshape(-1), dx.reshape(-1, C).double())
+    assert rel(dtok, ref_tok) < 1e-6
+    assert rel(dpos[:T], dx.double().sum(0)) < 1e-6 and torch.all(dpos[T:] == 0)
+    with pytest.raises(IndexError):
+        ops.embed_fwd(torch.zeros((1, T + 4), dtype=torch.long, device=dev), tok.to(dev), pos.to(dev))
+
+
+def test_casts_and_colsum(dev):
+    from oracle import rng_ref
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    W = torch.randn(80, 384, generator=g)
+    assert torch.equal(ops.cast(W.to(dev), torch.bfloat16).cpu(), W.bfloat16())
+    assert torch.equal(ops.cast(W.bfloat16().to(dev), torch.float32).cpu(), W.bfloat16().float())
+    Wt = ops.transpose_cast(W.to(dev), torch.bfloat16)
+    assert Wt.shape == (384, 80) and torch.equal(Wt.cpu(), W.T.bfloat16())
+    W2 = torch.randn(50, 36, generator=g)
+    Wt2 = ops.transpose_cast(W2.to(dev), torch.float32)       # R=50 -> ld 52, zero padded
+    assert Wt2.shape == (36, 52) and torch.equal(Wt2[:, :50].cpu(), W2.T) and torch.all(Wt2[:, 50:] == 0)
+    # dropout backward + cast + column sums
+    M, N, p = 1000, 384, 0.2
+    dy = torch.randn(M, N, generator=g)
+    seed, step, site = 5, 0, 2
+    rng = ops.new_rng_state(seed, dev, step)
+    G = 31
+    part = torch.empty(G, N, device=dev)
+    gq = ops.dropout_bwd_cast(dy.to(dev), torch.float32, p, rng, site, colsum_part=part, part_stride=N, n_partials=G)
+    keep = torch.from_numpy(rng_ref.keep_mask(seed, step, site, p, M * N).reshape(M, N))
+    ref = dy * keep / (1 - p)
+    assert rel(gq, ref) < 1e-6
+    cs = torch.empty(N, device=dev)
+    ops.reduce_partials(part, N, G, cs, N)
+    assert rel(cs, ref.double().sum(0)) < 1e-5
+    mask = torch.randn(M, N, generator=g)
+    gm = ops.dropout_bwd_cast(dy.to(dev), torch.bfloat16, 0.0, None, 0, relu_mask=mask.to(dev))
+    assert torch.equal(gm.cpu(), (dy * (mask > 0)).bfloat16())
+    part2 = torch.empty(G, N, device=dev)
+    ops.colsum(dy.bfloat16().to(dev), part2, N, G)
+    ops.reduce_partials(part2, N, G, cs, N)
+    assert rel(cs, dy.bfloat16().double().sum(0)) < 1e-5
+
+
+def test_adamw_matches_oracle(dev):
+    from oracle import drake_ref as R
+    ops = _ops()
+    n = 10007
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(n, generator=g)
+    params = {"w": p0.clone()}
+    opt = R.AdamWState(["w"], 1e-3, (0.9, 0.95))
+    pd = p0.clone().to(dev)
+    pad = (n + 3) // 4 * 4
+    m = torch.zeros(pad, device=dev)[:n]
+    v = torch.zeros(pad, device=dev)[:n]
+    hyper = torch.tensor([1e-3, 0.9, 0.95, 1e-8, 1e-2], device=dev)
+    st = ops.new_rng_state(0, dev, 0)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    for it in range(4):
+        gr = torch.randn(n, generator=g)
+        opt.step(params, {"w": gr})
+        ops.adamw_step(pd, gr.to(dev), m, v, hyper, st, shadow_bf16=shadow)
+        ops.state_advance(st)
+    assert maxabs(pd, params["w"]) < 2e-6
+    assert torch.equal(shadow.cpu(), pd.cpu().bfloat16())
+
+
+def test_batch_gather_and_softmax(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    data = torch.randint(0, 80, (5000,), generator=g)
+    off = torch.randint(5000 - 8, (32,), generator=g)
+    x, y = ops.batch_gather(data.to(dev), off.to(dev), 8)
+    assert torch.equal(x.cpu(), torch.stack([data[i:i + 8] for i in off]))
+    assert torch.equal(y.cpu(), torch.stack([data[i + 1:i + 9] for i in off]))
+    logits = torch.randn(3, 5, 80, generator=g).to(dev)
+    pr = ops.softmax_rows(logits[:, -1, :])
+    assert rel(pr, logits[:, -1, :].double().softmax(-1)) < 1e-6
