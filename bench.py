@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training tokens/s of TransformerLM_scaled (fwd + bwd + AdamW) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config scaled] [--batch B] [--precision bf16]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+(one process per GPU, RCCL): weak scaling, every rank trains B_local rows of the same global batch and
+the flat gradient is all-reduced once per step.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): TransformerLM_scaled = V 80, C 384, T 256, 6 heads, 6 blocks,
+dropout 0.2 (src/config.py:27-38), batch 64 per GPU, synthetic uniform char corpus of 1e6 tokens
+(seed 42), random-init weights (torch default initialisers, seed 42), bf16 MFMA operands with
+fp32 accumulation / master weights.  Inputs (corpus, window offsets) are resident in HBM when the
+timed region starts.
+
+roofline: the MFMA-bound kernel symbol that takes the most time in the step; `achieved` is its
+algorithmic FLOP per launch / its average launch duration, both taken live with HIP events on the
+launch stream in an eager (un-captured) replay of the same step.  cpu_baseline: the CPU oracle
+(oracle/drake_ref.py, bit-identical to the reference) timed on this host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (guides/MI355X_MICROARCH.md: ~2.5 PF)
+PEAK_F32_TFLOPS = 157.3        # fp32 MFMA = vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_token(cfg, V):
+    """algorithmic FLOP of one training step per token, causal attention counted at the work
+    actually required: F_step = 3 * [L (24 C^2 + 2 (T+1) C) + 2 C V]"""
+    C, T, L = cfg["embedding_dim"], cfg["context_length"], cfg["num_layers"]
+    return 3 * (L * (24 * C * C + 2 * (T + 1) * C) + 2 * C * V)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="scaled")
+    ap.add_argument("--batch", type=int, default=None, help="rows per GPU (default: the preset's batch_size)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+
+    import drakegpt_amd as D
+    from drakegpt_amd.config import DRAKE_VOCAB_SIZE, PRESETS
+    from drakegpt_amd.engine import TrainEngine
+
+    cfg = PRESETS[args.config]
+    V = cfg.get("vocab_size", DRAKE_VOCAB_SIZE)
+    B = args.batch or cfg["batch_size"]
+    T = cfg["context_length"]
+    torch.manual_seed(42)
+    model = D.TransformerLM(V, cfg["embedding_dim"], T, cfg["num_heads"], cfg["num_layers"], cfg["dropout"],
+                            precision=args.precision).to(dev)
+    eng = TrainEngine(model, B, T, lr=cfg["base_lr"], betas=cfg["betas"], seed=42, rank=rank, world_size=world,
+                      process_group=pg, use_graph=not args.no_graph)
+    n_corpus = 1_000_000 if V <= 256 else 10_000_000
+    corpus = torch.randint(0, V, (n_corpus,), generator=torch.Generator().manual_seed(42))
+    eng.set_corpus(corpus)
+    # window offsets: the global batch is drawn by the host CPU generator exactly as get_batch does
+    # (src/preprocessing.py:43); rank r takes rows [r*B, (r+1)*B).  Staged in HBM before timing.
+    gen = torch.Generator().manual_seed(42)
+    total = args.warmup + args.steps
+    offs = torch.stack([torch.randint(n_corpus - T, (B * world,), generator=gen)[rank * B:(rank + 1) * B] for _ in range(total)])
+    offs = offs.to(dev)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    if rank == 0:
+        log(f"warm-up ({args.warmup} steps, graph capture on the first)")
+    for i in range(args.warmup):
+        eng.set_offsets(offs[i])
+        eng.step()
+    barrier()
+    if rank == 0:
+        log(f"timing {args.steps} steps")
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        eng.set_offsets(offs[i])
+        eng.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    final_loss = eng.loss.item()
+    tokens = args.steps * B * T * world
+    tok_s = tokens / dt
+    fpt = flops_per_token(cfg, V)
+    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+
+    if rank == 0:
+        log(f"{tok_s:.0f} tokens/s, {1e3 * dt / args.steps:.3f} ms/step, loss {final_loss:.4f}")
+    roofline = None
+    if rank == 0 and not args.no_kernel_timing:
+        roofline = kernel_roofline(eng, offs[0], peak)
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = cpu_baseline_leg(args.config, cfg, V)
+
+    if rank == 0:
+        out = {
+            "metric": "training tokens/sec (fwd+bwd+AdamW)", "value": tok_s, "unit": "tokens/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"TransformerLM_{args.config}: V={V} C={cfg['embedding_dim']} T={T} heads={cfg['num_heads']} "
+                                   f"layers={cfg['num_layers']} dropout={cfg['dropout']}; fwd+bwd+AdamW; hipGraph={'off' if args.no_graph else 'on'}",
+                       "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
+                       "params": sum(p.numel() for p in model.parameters())},
+            "model_flops_per_token": fpt,
+            "achieved_tflops_per_gpu": tok_s * fpt / 1e12 / world,
+            "mfma_peak_frac_whole_step": tok_s * fpt / 1e12 / world / peak,
+            "final_loss": final_loss,
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def kernel_roofline(eng, offsets, peak_tflops):
+    """Time every MFMA GEMM launch of one step with HIP events (eager, on the launch stream) and
+    report the symbol with the largest total time."""
+    from drakegpt_amd import ops
+
+    records = []          # (symbol, flops, start_event, end_event)
+    real_nt, real_tn = ops.gemm_nt, ops.gemm_tn
+
+    def nt(A, Bm, out_dtype, **kw):
+        M = A.shape[0]
+        K = kw.get("K") or A.shape[1]
+        N = kw.get("N") or Bm.shape[0]
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = real_nt(A, Bm, out_dtype, **kw)
+        e.record()
+        sym = f"gemm_nt_kernel<{'bf16' if A.dtype == torch.bfloat16 else 'f32'},{'bf16' if out_dtype == torch.bfloat16 else 'f32'}>"
+        records.append((sym, 2.0 * M * N * K, s, e))
+        return r
+
+    def tn(A, Bm, out_part, split_stride, n_splits, P, Q, ldo=None):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        real_tn(A, Bm, out_part, split_stride, n_splits, P, Q, ldo)
+        e.record()
+        sym = "gemm_tn_bf16_kernel" if A.dtype == torch.bfloat16 else "gemm_tn_f32_kernel"
+        records.append((sym, 2.0 * A.shape[0] * P * Q, s, e))
+
+    eng.set_offsets(offsets)
+    ops.gemm_nt, ops.gemm_tn = nt, tn
+    try:
+        reps = 3
+        for _ in range(reps):
+            eng._prog_fwd_bwd()
+            eng._prog_update()
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_nt, ops.gemm_tn = real_nt, real_tn
+    agg = {}
+    for sym, fl, s, e in records:
+        a = agg.setdefault(sym, [0.0, 0.0, 0])
+        a[0] += fl
+        a[1] += s.elapsed_time(e) * 1e-3
+        a[2] += 1
+    sym, (fl, sec, n) = max(agg.items(), key=lambda kv: kv[1][1])
+    achieved = fl / sec / 1e12
+    return {"bound": "mfma", "kernel": sym, "achieved": achieved, "peak": peak_tflops, "unit": "TFLOP/s",
+            "frac": achieved / peak_tflops, "traffic": None, "launches_per_step": n // reps,
+            "avg_launch_us": 1e6 * sec / n, "flops_per_launch": fl / n,
+            "all_gemm_symbols": {k: {"tflops": v[0] / v[1] / 1e12, "avg_us": 1e6 * v[1] / v[2], "launches_per_step": v[2] // reps}
+                                 for k, v in agg.items()}}
+
+
+def usable_cores() -> int:
+    """CPU share of this process: min(affinity mask, cgroup quota, 16 -- the GPU box's share per GPU)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, 16))
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline_leg(config_name, cfg, V):
+    """the CPU oracle (== the reference's arithmetic) on this host: bounded sample of the workload"""
+    from oracle import drake_ref as R
+    ncores = usable_cores()
+    torch.set_num_threads(ncores)
+    log(f"cpu baseline on {ncores} threads")
+    B = 8 if cfg["embedding_dim"] >= 256 else cfg["batch_size"]
+    T = cfg["context_length"]
+    ocfg = dict(cfg)
+    sd = R.init_state_dict("TransformerLM", V, ocfg, seed=42)
+    opt = R.AdamWState(R.trainable_keys("TransformerLM", sd), cfg["base_lr"], cfg["betas"])
+    data = torch.randint(0, V, (100_000,), generator=torch.Generator().manual_seed(42))
+    gen = torch.Generator().manual_seed(42)
+    x, y = R.get_batch(data, T, B, gen)
+    R.train_step("TransformerLM", sd, opt, x, y, p=cfg["dropout"], training=True)       # untimed warm-up
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        x, y = R.get_batch(data, T, B, gen)
+        R.train_step("TransformerLM", sd, opt, x, y, p=cfg["dropout"], training=True)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or steps >= 200:
+            break
+        if steps % 2 == 0:
+            log(f"cpu baseline: {steps} steps, {el:.1f} s")
+    return {"value": steps * B * T / el, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} fwd+bwd+AdamW steps of TransformerLM_{config_name} at batch {B} x {T} tokens, fp32 torch CPU ops "
+                      f"(oracle/drake_ref.py, bit-identical to the reference), {el:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

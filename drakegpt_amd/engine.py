@@ -1,0 +1,381 @@
+"""Graph-captured training step for TransformerLM -- the performance path.
+
+One step = ref: src/train.py:143-151 (get_batch -> forward -> zero_grad -> backward -> AdamW.step)
+run as hand-sequenced HIP kernels with no autograd, captured once into a hipGraph and replayed:
+Python issues ~300 kernel launches at capture time and one graph launch per step afterwards.
+
+MI355X-first layout (288 GB HBM: keep everything resident, nothing is re-packed per step):
+  * ONE flat fp32 master buffer holds every parameter; the model's nn.Parameters (reference
+    state_dict layout, per-head key/query/value) are re-pointed to be VIEWS into it, with each
+    layer's heads laid out as one packed [3C, C] QKV operand.  Regions:
+        A  GEMM weights      (gradients arrive as S split-K slabs from the TN GEMMs)
+        B  biases, LayerNorm (gradients arrive as G row-chunk partials)
+        E  embeddings        (gradients written directly)
+        Z  ln_f              (exists for the checkpoint; no gradient, no optimizer update)
+  * flat gradient / Adam m / Adam v buffers with the same layout; one fused AdamW launch, which
+    also refreshes the bf16 shadow copy of the weights; W^T shadows (dX operands) are refreshed by
+    one transpose launch per matrix;
+  * step counter, dropout seed and learning rate live in device memory so a replay sees fresh
+    dropout masks, the right bias correction and the scheduler's current lr;
+  * data parallel: the flat gradient is all-reduced (RCCL via torch.distributed) between the
+    backward graph and the optimizer graph; ln_f is outside the reduced range on every rank.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from . import sublayers as S
+from .model import TransformerLM
+
+Tensor = torch.Tensor
+ALIGN = 64          # floats: every tensor starts on a 256-byte boundary of the flat buffer
+
+
+def _round(n: int, a: int = ALIGN) -> int:
+    return (n + a - 1) // a * a
+
+
+class _Layout:
+    def __init__(self):
+        self.entries: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.size = 0
+
+    def add(self, key: str, shape) -> int:
+        off = self.size
+        n = 1
+        for d in shape:
+            n *= d
+        self.entries[key] = (off, tuple(shape))
+        self.size = off + _round(n)
+        return off
+
+
+class ShadowWeights:
+    """persistent GEMM operands: bf16 (or the fp32 master itself) for forward, W^T for dX"""
+
+    def __init__(self):
+        self.fwd_map: Dict[int, Tensor] = {}
+        self.bwd_map: Dict[int, Tensor] = {}
+
+    def fwd(self, W: Tensor) -> Tensor:
+        return self.fwd_map[W.data_ptr()]
+
+    def bwd(self, W: Tensor) -> Tensor:
+        return self.bwd_map[W.data_ptr()]
+
+
+class FlatSink:
+    def __init__(self, eng: "TrainEngine"):
+        self.e = eng
+
+    def matrix(self, key, P, Q):
+        off, shape = self.e.layA.entries[key]
+        assert shape == (P, Q), (key, shape, P, Q)
+        return self.e.slabs[0, off:off + P * Q], self.e.layA.size, self.e.S
+
+    def vector(self, key, N):
+        off, shape = self.e.layB.entries[key]
+        assert shape == (N,), (key, shape, N)
+        return self.e.vparts[0, off:off + N], self.e.layB.size, self.e.G
+
+    def direct(self, key, shape=None):
+        return self.e.grad_view(key)
+
+
+class TrainEngine:
+    def __init__(self, model: TransformerLM, batch_size: int, context_length: Optional[int] = None, *,
+                 lr: float = 1e-3, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 seed: int = 42, rank: int = 0, world_size: int = 1, process_group=None, use_graph: bool = True):
+        if not isinstance(model, TransformerLM):
+            raise TypeError("TrainEngine drives TransformerLM (the other five models train through the autograd path)")
+        p0 = next(model.parameters())
+        if not p0.is_cuda:
+            raise RuntimeError("TrainEngine needs the model on the GPU (model.to('cuda')); there is no CPU path")
+        self.model = model
+        self.dev = p0.device
+        self.act = model.act_dtype
+        self.B = int(batch_size)
+        self.T = int(context_length or model.context_length)
+        if self.T > model.context_length:
+            raise ValueError("context_length exceeds the model's position table")
+        self.V, self.C = model.token_embedding_table.weight.shape
+        self.L = len(model.blocks)
+        blk0 = model.blocks[0]
+        self.NH = len(blk0.sa_head.heads)
+        self.H = blk0.sa_head.heads[0].head_size
+        self.p_drop = float(model._p)
+        self.M = self.B * self.T
+        self.rank, self.world, self.pg = rank, world_size, process_group
+        self.use_graph = use_graph
+        g = S.granule(self.act)
+        if self.C % g or (self.NH * self.H) % g:
+            raise ValueError(f"embedding_dim must be a multiple of {g} for {self.act}")
+        self.S = S.n_splits_for(self.M)
+        self.G = S.n_partials_for(self.M)
+        self._build_layout()
+        self._alloc_and_adopt()
+        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay], dtype=torch.float32, device=self.dev)
+        # dropout stream differs per data-parallel rank; the step word also drives Adam's bias correction
+        self.state = ops.new_rng_state(seed + 0x9E3779B97F4A7C15 * rank & 0xFFFFFFFFFFFFFFFF, self.dev, 0)
+        self.offsets = torch.zeros((self.B,), dtype=torch.int64, device=self.dev)
+        self.x = torch.zeros((self.B, self.T), dtype=torch.int64, device=self.dev)
+        self.y = torch.zeros((self.B, self.T), dtype=torch.int64, device=self.dev)
+        self.loss = torch.zeros((), dtype=torch.float32, device=self.dev)
+        self.corpus: Optional[Tensor] = None
+        self._graphs = None
+        self.refresh_shadows()
+
+    # -------------------------------------------------------------------------------- layout
+    def _build_layout(self):
+        C, V, L, NH, H = self.C, self.V, self.L, self.NH, self.H
+        A, Bv, E, Z = _Layout(), _Layout(), _Layout(), _Layout()
+        for l in range(L):
+            A.add(f"{l}.wqkv", (3 * NH * H, C))
+            A.add(f"{l}.wproj", (C, NH * H))
+            A.add(f"{l}.w1", (4 * C, C))
+            A.add(f"{l}.w2", (C, 4 * C))
+        A.add("lm.w", (V, C))
+        for l in range(L):
+            for k, n in (("bproj", C), ("b1", 4 * C), ("b2", C), ("ln1w", C), ("ln1b", C), ("ln2w", C), ("ln2b", C)):
+                Bv.add(f"{l}.{k}", (n,))
+        Bv.add("lm.b", (V,))
+        E.add("tok", (V, C))
+        E.add("pos", (self.model.context_length, C))
+        Z.add("lnf.w", (C,))
+        Z.add("lnf.b", (C,))
+        self.layA, self.layB, self.layE, self.layZ = A, Bv, E, Z
+        self.offA, self.offB = 0, A.size
+        self.offE = A.size + Bv.size
+        self.n_active = self.offE + E.size           # optimizer / all-reduce range
+        self.offZ = self.n_active
+        self.n_total = self.n_active + Z.size
+
+    def _region(self, key: str):
+        for lay, base in ((self.layA, self.offA), (self.layB, self.offB), (self.layE, self.offE), (self.layZ, self.offZ)):
+            if key in lay.entries:
+                off, shape = lay.entries[key]
+                return base + off, shape
+        raise KeyError(key)
+
+    def param_view(self, key: str) -> Tensor:
+        off, shape = self._region(key)
+        n = 1
+        for d in shape:
+            n *= d
+        return self.flat[off:off + n].view(shape)
+
+    def grad_view(self, key: str) -> Tensor:
+        off, shape = self._region(key)
+        n = 1
+        for d in shape:
+            n *= d
+        return self.gflat[off:off + n].view(shape)
+
+    def _alloc_and_adopt(self):
+        """copy the model's current weights into the flat buffer and re-point its Parameters at it"""
+        dev, m = self.dev, self.model
+        self.flat = torch.zeros(self.n_total, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
+        self.m_ = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
+        self.v_ = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
+        self.slabs = torch.zeros((self.S, self.layA.size), dtype=torch.float32, device=dev)
+        self.vparts = torch.zeros((self.G, self.layB.size), dtype=torch.float32, device=dev)
+        NH, H = self.NH, self.H
+
+        def adopt(param: torch.nn.Parameter, view: Tensor):
+            view.copy_(param.data)
+            param.data = view
+
+        with torch.no_grad():
+            for l, blk in enumerate(m.blocks):
+                wqkv = self.param_view(f"{l}.wqkv")
+                for h, head in enumerate(blk.sa_head.heads):
+                    adopt(head.query.weight, wqkv[h * H:(h + 1) * H])
+                    adopt(head.key.weight, wqkv[(NH + h) * H:(NH + h + 1) * H])
+                    adopt(head.value.weight, wqkv[(2 * NH + h) * H:(2 * NH + h + 1) * H])
+                adopt(blk.sa_head.proj.weight, self.param_view(f"{l}.wproj"))
+                adopt(blk.sa_head.proj.bias, self.param_view(f"{l}.bproj"))
+                adopt(blk.ffwd.net[0].weight, self.param_view(f"{l}.w1"))
+                adopt(blk.ffwd.net[0].bias, self.param_view(f"{l}.b1"))
+                adopt(blk.ffwd.net[2].weight, self.param_view(f"{l}.w2"))
+                adopt(blk.ffwd.net[2].bias, self.param_view(f"{l}.b2"))
+                adopt(blk.ln1.weight, self.param_view(f"{l}.ln1w"))
+                adopt(blk.ln1.bias, self.param_view(f"{l}.ln1b"))
+                adopt(blk.ln2.weight, self.param_view(f"{l}.ln2w"))
+                adopt(blk.ln2.bias, self.param_view(f"{l}.ln2b"))
+            adopt(m.lm_head.weight, self.param_view("lm.w"))
+            adopt(m.lm_head.bias, self.param_view("lm.b"))
+            adopt(m.token_embedding_table.weight, self.param_view("tok"))
+            adopt(m.position_embedding_table.weight, self.param_view("pos"))
+            adopt(m.ln_f.weight, self.param_view("lnf.w"))
+            adopt(m.ln_f.bias, self.param_view("lnf.b"))
+        # GEMM operand shadows
+        self.weights = ShadowWeights()
+        self.shadow = None
+        if self.act == torch.bfloat16:
+            self.shadow = torch.zeros(self.n_active, dtype=torch.bfloat16, device=dev)
+        self._mats: List[Tuple[Tensor, Tensor]] = []
+        gr = S.granule(self.act)
+        for key, (off, shape) in self.layA.entries.items():
+            W = self.param_view(key)
+            n = shape[0] * shape[1]
+            if self.shadow is not None:
+                self.weights.fwd_map[W.data_ptr()] = self.shadow[self.offA + off:self.offA + off + n].view(shape)
+            else:
+                self.weights.fwd_map[W.data_ptr()] = W
+            Wt = torch.zeros((shape[1], S.pad_to(shape[0], gr)), dtype=self.act, device=dev)
+            self.weights.bwd_map[W.data_ptr()] = Wt
+            self._mats.append((W, Wt))
+
+    def refresh_shadows(self):
+        """bf16 copy of the GEMM weights + every W^T.  Call after the weights change outside step()
+        (load_state_dict, manual edits); step() keeps them current by itself."""
+        if self.shadow is not None:
+            ops.cast(self.flat[:self.layA.size], torch.bfloat16, out=self.shadow[:self.layA.size])
+        self._refresh_transposes()
+
+    def _refresh_transposes(self):
+        for W, Wt in self._mats:
+            ops.transpose_cast(W, self.act, ldo=Wt.shape[1], out=Wt)
+
+    # -------------------------------------------------------------------------------- programs
+    def _layer_params(self, l: int):
+        pv = self.param_view
+        return dict(ln1w=pv(f"{l}.ln1w"), ln1b=pv(f"{l}.ln1b"), wqkv=pv(f"{l}.wqkv"), wproj=pv(f"{l}.wproj"),
+                    bproj=pv(f"{l}.bproj"), ln2w=pv(f"{l}.ln2w"), ln2b=pv(f"{l}.ln2b"), w1=pv(f"{l}.w1"), b1=pv(f"{l}.b1"),
+                    w2=pv(f"{l}.w2"), b2=pv(f"{l}.b2"))
+
+    def _forward(self, run: S.Run, x_idx: Tensor, y_idx: Optional[Tensor], want_grad: bool):
+        B, T = x_idx.shape
+        M = B * T
+        p = self.p_drop
+        h = ops.embed_fwd(x_idx, self.param_view("tok"), self.param_view("pos")).view(M, self.C)
+        saved = []
+        for l in range(self.L):
+            P = self._layer_params(l)
+            h, sa = S.attn_fwd(run, h, P["ln1w"], P["ln1b"], P["wqkv"], P["wproj"], P["bproj"], True, B, T, self.NH, self.H, p, p, l)
+            h, sf = S.ffn_fwd(run, h, P["ln2w"], P["ln2b"], P["w1"], P["b1"], P["w2"], P["b2"], True, p, l)
+            if want_grad:
+                saved.append((sa, sf))
+        logits, (xa,) = S.linear_fwd(run, h, self.param_view("lm.w"), self.param_view("lm.b"))
+        if y_idx is None:
+            return logits, None, None
+        dlogits = None
+        if want_grad:
+            dlogits = torch.empty((M, S.pad_to(self.V, S.granule(self.act))), dtype=self.act, device=self.dev)
+        rows = ops.cross_entropy(logits, y_idx.view(M), self.V, dlogits=dlogits, grad_scale=1.0 / M)
+        return logits, rows, (saved, xa, dlogits)
+
+    def _backward(self, run: S.Run, x_idx: Tensor, ctx):
+        saved, xa, dlogits = ctx
+        B, T = x_idx.shape
+        p = self.p_drop
+        sink = FlatSink(self)
+        dh = S.linear_bwd_from_act(run, (xa,), dlogits[:, :self.V], self.param_view("lm.w"), True, sink, {"w": "lm.w", "b": "lm.b"})
+        for l in reversed(range(self.L)):
+            P = self._layer_params(l)
+            sa, sf = saved[l]
+            dh = S.ffn_bwd(run, sf, dh, P["ln2w"], P["w1"], P["w2"], True, p, l, sink,
+                           {"w1": f"{l}.w1", "b1": f"{l}.b1", "w2": f"{l}.w2", "b2": f"{l}.b2", "ln_w": f"{l}.ln2w", "ln_b": f"{l}.ln2b"})
+            dh = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink,
+                            {"wqkv": f"{l}.wqkv", "wproj": f"{l}.wproj", "bproj": f"{l}.bproj", "ln_w": f"{l}.ln1w", "ln_b": f"{l}.ln1b"})
+        ops.embed_bwd(x_idx, dh.view(B, T, self.C), self.grad_view("tok"), self.grad_view("pos")[:T])
+        ops.reduce_partials(self.slabs, self.layA.size, self.S, self.gflat[self.offA:], self.layA.size)
+        ops.reduce_partials(self.vparts, self.layB.size, self.G, self.gflat[self.offB:], self.layB.size)
+
+    def _prog_fwd_bwd(self):
+        """gather the batch, forward, backward, reduce the gradient partials"""
+        if self.corpus is not None:
+            ops.batch_gather(self.corpus, self.offsets, self.T, self.x, self.y)
+        run = S.Run(act=self.act, rng=self.state if self.p_drop > 0.0 else None, weights=self.weights)
+        _, rows, ctx = self._forward(run, self.x, self.y, True)
+        ops.reduce_sum(rows, 1.0 / self.M, out=self.loss)
+        self._backward(run, self.x, ctx)
+
+    def _prog_update(self):
+        ops.adamw_step(self.flat, self.gflat, self.m_, self.v_, self.hyper, self.state, 1.0 / self.world,
+                       shadow_bf16=self.shadow, n=self.n_active)
+        self._refresh_transposes()
+        ops.state_advance(self.state)
+
+    def _allreduce(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)     # mean = sum * 1/world in AdamW
+
+    # -------------------------------------------------------------------------------- capture
+    def _capture(self):
+        snap = (self.flat.clone(), self.m_.clone(), self.v_.clone(), self.state.clone())
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):       # warm-up: loads every code object before capture
+            self._prog_fwd_bwd()
+            self._prog_update()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self.flat.copy_(snap[0]); self.m_.copy_(snap[1]); self.v_.copy_(snap[2]); self.state.copy_(snap[3])
+        self.refresh_shadows()
+        torch.cuda.synchronize(self.dev)
+        if self.world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._prog_fwd_bwd()
+                self._prog_update()
+            self._graphs = (g,)
+        else:
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._prog_fwd_bwd()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._prog_update()
+            self._graphs = (g1, g2)
+
+    # -------------------------------------------------------------------------------- public
+    def set_corpus(self, data: Tensor):
+        """keep the token stream resident in HBM (int64, as train_data.pt stores it)"""
+        self.corpus = data.to(self.dev, dtype=torch.int64).contiguous()
+        self._graphs = None
+
+    def set_lr(self, lr: float):
+        self.hyper[0:1].fill_(float(lr))
+
+    def set_offsets(self, ix: Tensor):
+        """window offsets of THIS rank's rows (drawn by the host CPU generator, ref: preprocessing.py:43)"""
+        if ix.is_cuda:
+            self.offsets.copy_(ix, non_blocking=True)      # stream-ordered device copy
+        else:
+            self.offsets.copy_(ix)                         # synchronous: stage blocks of offsets in HBM instead
+
+    def set_batch(self, x: Tensor, y: Tensor):
+        self.x.copy_(x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+
+    def step(self) -> Tensor:
+        """one training iteration on the current offsets / batch; returns the device loss scalar"""
+        if not self.use_graph:
+            self._prog_fwd_bwd()
+            self._allreduce()
+            self._prog_update()
+            return self.loss
+        if self._graphs is None:
+            self._capture()
+        if self.world == 1:
+            self._graphs[0].replay()
+        else:
+            self._graphs[0].replay()
+            self._allreduce()
+            self._graphs[1].replay()
+        return self.loss
+
+    @torch.no_grad()
+    def eval_loss(self, x: Tensor, y: Tensor) -> Tensor:
+        """forward only, dropout off (ref: evaluate_loss, src/train.py:61-75)"""
+        run = S.Run(act=self.act, rng=None, weights=self.weights)
+        _, rows, _ = self._forward(run, x, y, False)
+        return ops.reduce_sum(rows, 1.0 / rows.numel())
+
+    def step_count(self) -> int:
+        return int(self.state[2].item())
