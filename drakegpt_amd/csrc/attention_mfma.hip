@@ -1,7 +1,454 @@
-// bf16 MFMA flash attention for head size 64 -- placeholder until the kernels land: reports
-// "unsupported" so dg_attn_* routes every shape to the generic kernels.
+// bf16 MFMA flash attention for head size 64 (forward, dQ, dK/dV), causal, with in-kernel dropout.
+// ref: Head2.forward src/model_component.py:392-405 for every head of MultiHeadAttention3.
+//
+// Design (gfx950, wave64, v_mfma_f32_32x32x16_bf16):
+//  * one wave owns a 32-row block (queries in fwd/dQ, keys in dK/dV) and walks the 32-row tiles of
+//    the other side that the causal mask leaves; the (T,T) score matrix never exists in memory;
+//  * forward and dQ compute the TRANSPOSED score tile S^T = K Q^T, so a lane holds one query column:
+//    row max / row sum / lse / delta are lane-local (one cross-half shuffle), and the exponentiated
+//    tile, converted to bf16 in registers, IS the B operand of the next MFMA (O^T = V^T P^T,
+//    dQ^T = K^T dS^T) -- no LDS round trip for P (guide section 3, "accumulator tile as operand");
+//  * dK/dV computes S = Q K^T with the key on the lane; P and dS are then the A operands (X^T) of
+//    dV = Pd^T dO and dK = dS^T Q;
+//  * operands whose contraction index is the strided one (V, K in dQ, Q and dO in dK/dV) are read
+//    from LDS with ds_read_b64_tr_b16 (hardware transpose); row-read operands use ds_read_b128 on an
+//    XOR-swizzled image.  Every wave has a private LDS slice: no workgroup barriers at all;
+//  * the next tile's global loads are issued before the current tile's MFMAs (register prefetch);
+//  * dropout keep = hash(seed, step, site, ((b*NH+h)*T+i)*T+j), regenerated in backward.
+// Scores per (b,h): T*(T+1)/2; FLOP per score element: fwd 4*64, bwd 10*64 (+2 recomputed products
+// because dQ and dK/dV are separate deterministic passes: no atomics, bitwise reproducible).
 #include "common.h"
-bool dg_attn_mfma_supported(int, int, int, int) { return false; }
-int dg_attn_fwd_mfma(const void*, void*, float*, int, int, int, int, float, float, const uint32_t*, uint32_t, hipStream_t) { return DG_ERR_ARG; }
-int dg_attn_bwd_mfma(const void*, const void*, const void*, const float*, void*, float*, int, int, int, int, float, float,
-                     const uint32_t*, uint32_t, hipStream_t) { return DG_ERR_ARG; }
+
+#define HD 64
+#define TILE 32
+#define LOG2E 1.4426950408889634f
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+
+struct AttnP {
+    const bf16_t* qkv; const bf16_t* out; const bf16_t* dout;
+    bf16_t* out_w; bf16_t* dqkv;
+    float* lse; const float* lse_r; float* delta; const float* delta_r;
+    int B, T, NH, nblk;
+    int64_t n_items;
+    float scale;
+    int drop; float inv_keep; uint32_t thr; const uint32_t* rng; uint32_t site;
+};
+
+__device__ __forceinline__ int krow(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+// [32 rows][128 B] images.  row image: ds_read_b128 by 32 rows at one chunk is conflict-free
+__device__ __forceinline__ int off_row(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+// transposed-read image: a half-wave's 4 rows x 4 chunks land on 16 distinct 16-byte slots
+__device__ __forceinline__ int off_tr(int row, int ch) { return row * 128 + ((ch ^ (((row >> 1) & 1) << 2)) << 4); }
+
+// global [rows][HD] tile (row stride ld elements) -> 4 x 16 B per lane, rows >= T zero-filled
+__device__ __forceinline__ void tile_load(u32x4 (&r)[4], const bf16_t* base, int64_t ld, int row0, int T, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i, row = c >> 3, ch = c & 7;
+        const int gr = row0 + row;
+        r[i] = (gr < T) ? *(const u32x4*)(base + (int64_t)gr * ld + ch * 8) : (u32x4){0u, 0u, 0u, 0u};
+    }
+}
+template <bool TR>
+__device__ __forceinline__ void tile_store(char* img, const u32x4 (&r)[4], int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i, row = c >> 3, ch = c & 7;
+        *(u32x4*)(img + (TR ? off_tr(row, ch) : off_row(row, ch))) = r[i];
+    }
+}
+// A/B fragment by rows: element j = tile[lane&31][16*ks + 8*hh + j]
+__device__ __forceinline__ bf16x8 frag_row(const char* img, int ks, int lane) {
+    return __builtin_bit_cast(bf16x8, *(const u32x4*)(img + off_row(lane & 31, 2 * ks + (lane >> 5))));
+}
+// fragment by columns for the accumulator-as-operand products: element j of lane (col = 32*dt + lane&31,
+// half hh) = tile[16*s + 8*(j>>2) + 4*hh + (j&3)][col]   (the k permutation of the 32x32 C/D map)
+__device__ __forceinline__ bf16x8 frag_tr(const char* img, int dt, int s, int lane) {
+    const int i = lane & 15, q = i >> 2, pp = i & 3, hh = lane >> 5;
+    const int col = dt * 32 + 16 * ((lane >> 4) & 1) + 4 * pp;
+    const int ch = col >> 3, inb = (col & 7) * 2;
+    const int ra = 16 * s + 4 * hh + q, rb = ra + 8;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(img + off_tr(ra, ch) + inb));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)(img + off_tr(rb, ch) + inb));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)x[8 * s + j];
+    return r;
+}
+// direct global fragment (rows on lanes): element j = M[row0 + lane&31][16*ks + 8*hh + j]
+__device__ __forceinline__ void frags_global(bf16x8 (&f)[4], const bf16_t* base, int64_t ld, int row0, int T, int lane) {
+    const int gr = row0 + (lane & 31), hh = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        u32x4 v = (gr < T) ? *(const u32x4*)(base + (int64_t)gr * ld + 16 * ks + 8 * hh) : (u32x4){0u, 0u, 0u, 0u};
+        f[ks] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+// store a transposed accumulator pair (acc[dt][reg]: row d = 32*dt + krow(reg,hh), col = query lane&31)
+// as rows [32 queries][64 d] bf16 through the wave's LDS slice
+__device__ __forceinline__ void store_T_acc(char* img, const f32x16 (&acc)[2], float mul_lane, bf16_t* base, int64_t ld,
+                                            int row0, int T, int lane) {
+    const int c = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (bf16_t)(acc[dt][4 * g + j] * mul_lane);
+            const int d = 32 * dt + 8 * g + 4 * hh;            // 4 consecutive d
+            *(bf16x4*)(img + c * 128 + d * 2) = v;
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = lane + 64 * i, row = cc >> 3, ch = cc & 7;
+        const int gr = row0 + row;
+        u32x4 v = *(const u32x4*)(img + row * 128 + ch * 16);
+        if (gr < T) *(u32x4*)(base + (int64_t)gr * ld + ch * 8) = v;
+    }
+}
+// store an accumulator pair with rows on regs and d on lanes (acc[dt][reg]: row = krow(reg,hh), col d = 32*dt + lane&31)
+__device__ __forceinline__ void store_N_acc(char* img, const f32x16 (&acc)[2], float mul, bf16_t* base, int64_t ld,
+                                            int row0, int T, int lane) {
+    const int c = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *(bf16_t*)(img + krow(r, hh) * 128 + (32 * dt + c) * 2) = (bf16_t)(acc[dt][r] * mul);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = lane + 64 * i, row = cc >> 3, ch = cc & 7;
+        const int gr = row0 + row;
+        u32x4 v = *(const u32x4*)(img + row * 128 + ch * 16);
+        if (gr < T) *(u32x4*)(base + (int64_t)gr * ld + ch * 8) = v;
+    }
+}
+
+#define WAVE_LDS_FWD 8192
+// =============================================================================================
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= p.n_items) return;
+    char* imgK = smem + wave * WAVE_LDS_FWD;
+    char* imgV = imgK + 4096;
+    const int qb = p.nblk - 1 - (int)(item % p.nblk);          // heavy blocks first
+    const int64_t bh = item / p.nblk;
+    const int h = (int)(bh % p.NH), b = (int)(bh / p.NH);
+    const int T = p.T, C = p.NH * HD;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16_t* Qb = p.qkv + (int64_t)b * T * ld + h * HD;
+    const bf16_t* Kb = Qb + C;
+    const bf16_t* Vb = Qb + 2 * C;
+    const int q0 = qb * TILE, c = lane & 31, hh = lane >> 5;
+    const int qi = q0 + c;
+
+    bf16x8 qf[4];
+    frags_global(qf, Qb, ld, q0, T, lane);
+    f32x16 O[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { O[0][i] = 0.f; O[1][i] = 0.f; }
+    float m = -INFINITY, lsum = 0.f;
+    const float sc = p.scale * LOG2E;
+    const uint32_t key = p.drop ? dg_site_key_dev(p.rng, p.site) : 0u;
+    const uint32_t ebase = (uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T);
+
+    u32x4 rk[4], rv[4];
+    tile_load(rk, Kb, ld, 0, T, lane);
+    tile_load(rv, Vb, ld, 0, T, lane);
+    for (int kt = 0; kt <= qb; ++kt) {
+        tile_store<false>(imgK, rk, lane);
+        tile_store<true>(imgV, rv, lane);
+        if (kt < qb) {
+            tile_load(rk, Kb, ld, (kt + 1) * TILE, T, lane);
+            tile_load(rv, Vb, ld, (kt + 1) * TILE, T, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x16 S;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgK, ks, lane), qf[ks], S, 0, 0, 0);
+        const int k0 = kt * TILE;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = S[r] * sc;
+            if (kt == qb && k0 + krow(r, hh) > qi) s = -INFINITY;
+            S[r] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float e = exp2f(S[r] - mn);
+            ps += e;
+            if (p.drop) e = dg_keep(key, ebase + (uint32_t)(k0 + krow(r, hh)), p.thr) ? e * p.inv_keep : 0.f;
+            S[r] = e;
+        }
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { O[0][i] *= alpha; O[1][i] *= alpha; }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 pf = pack8(S, s);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(imgV, dt, s, lane), pf, O[dt], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (hh == 0 && qi < T) p.lse[bh * T + qi] = (m + log2f(lsum)) * (1.f / LOG2E);
+    store_T_acc(imgK, O, 1.f / lsum, p.out_w + (int64_t)b * T * C + h * HD, C, q0, T, lane);
+}
+
+// =============================================================================================
+// delta[b,h,i] = sum_d dO[i,d] * O[i,d]
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, float* __restrict__ delta,
+                                  int B, int T, int NH) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (b, t, h) with h fastest
+    const int64_t n = (int64_t)B * T * NH;
+    if (gid >= n) return;
+    const int h = (int)(gid % NH);
+    const int64_t bt = gid / NH;
+    const int64_t t = bt % T, b = bt / T;
+    const bf16_t* o = out + bt * (NH * HD) + h * HD;
+    const bf16_t* g = dout + bt * (NH * HD) + h * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        bf16x8 a = __builtin_bit_cast(bf16x8, *(const u32x4*)(o + 8 * i));
+        bf16x8 d = __builtin_bit_cast(bf16x8, *(const u32x4*)(g + 8 * i));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)d[j];
+    }
+    delta[(b * NH + h) * T + t] = s;
+}
+
+// =============================================================================================
+// dQ: wave = 32 queries; per key tile: S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T
+#define WAVE_LDS_DQ 12288
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= p.n_items) return;
+    char* imgK = smem + wave * WAVE_LDS_DQ;      // row image of K
+    char* imgKt = imgK + 4096;                   // transposed-read image of K
+    char* imgV = imgK + 8192;                    // row image of V
+    const int qb = p.nblk - 1 - (int)(item % p.nblk);
+    const int64_t bh = item / p.nblk;
+    const int h = (int)(bh % p.NH), b = (int)(bh / p.NH);
+    const int T = p.T, C = p.NH * HD;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16_t* Qb = p.qkv + (int64_t)b * T * ld + h * HD;
+    const bf16_t* Kb = Qb + C;
+    const bf16_t* Vb = Qb + 2 * C;
+    const bf16_t* dOb = p.dout + (int64_t)b * T * C + h * HD;
+    const int q0 = qb * TILE, c = lane & 31, hh = lane >> 5;
+    const int qi = q0 + c;
+
+    bf16x8 qf[4], gf[4];
+    frags_global(qf, Qb, ld, q0, T, lane);
+    frags_global(gf, dOb, C, q0, T, lane);
+    const float L2 = (qi < T) ? p.lse_r[bh * T + qi] * LOG2E : 0.f;
+    const float dl = (qi < T) ? p.delta_r[bh * T + qi] : 0.f;
+    f32x16 dQ[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dQ[0][i] = 0.f; dQ[1][i] = 0.f; }
+    const float sc = p.scale * LOG2E;
+    const uint32_t key = p.drop ? dg_site_key_dev(p.rng, p.site) : 0u;
+    const uint32_t ebase = (uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T);
+
+    u32x4 rk[4], rv[4];
+    tile_load(rk, Kb, ld, 0, T, lane);
+    tile_load(rv, Vb, ld, 0, T, lane);
+    for (int kt = 0; kt <= qb; ++kt) {
+        tile_store<false>(imgK, rk, lane);
+        tile_store<true>(imgKt, rk, lane);
+        tile_store<false>(imgV, rv, lane);
+        if (kt < qb) {
+            tile_load(rk, Kb, ld, (kt + 1) * TILE, T, lane);
+            tile_load(rv, Vb, ld, (kt + 1) * TILE, T, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x16 S, dP;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgK, ks, lane), qf[ks], S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgV, ks, lane), gf[ks], dP, 0, 0, 0);
+        }
+        const int k0 = kt * TILE;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kj = k0 + krow(r, hh);
+            float pr = exp2f(S[r] * sc - L2);
+            if (kt == qb && kj > qi) pr = 0.f;
+            float dp = dP[r];
+            if (p.drop) dp = dg_keep(key, ebase + (uint32_t)kj, p.thr) ? dp * p.inv_keep : 0.f;
+            S[r] = pr * (dp - dl);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 df = pack8(S, s);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(imgKt, dt, s, lane), df, dQ[dt], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    store_T_acc(imgK, dQ, p.scale, p.dqkv + (int64_t)b * T * ld + h * HD, ld, q0, T, lane);
+}
+
+// =============================================================================================
+// dK/dV: wave = 32 keys; per query tile: S = Q K^T, dP = dO V^T, dV += Pd^T dO, dK += dS^T Q
+#define WAVE_LDS_DKV 16384
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= p.n_items) return;
+    char* imgQ = smem + wave * WAVE_LDS_DKV;
+    char* imgQt = imgQ + 4096;
+    char* imgG = imgQ + 8192;
+    char* imgGt = imgQ + 12288;
+    const int kb = (int)(item % p.nblk);                     // low key blocks see the most queries: heavy first
+    const int64_t bh = item / p.nblk;
+    const int h = (int)(bh % p.NH), b = (int)(bh / p.NH);
+    const int T = p.T, C = p.NH * HD;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16_t* Qb = p.qkv + (int64_t)b * T * ld + h * HD;
+    const bf16_t* Kb = Qb + C;
+    const bf16_t* Vb = Qb + 2 * C;
+    const bf16_t* dOb = p.dout + (int64_t)b * T * C + h * HD;
+    const int k0 = kb * TILE, c = lane & 31, hh = lane >> 5;
+    const int kj = k0 + c;
+
+    bf16x8 kf[4], vf[4];
+    frags_global(kf, Kb, ld, k0, T, lane);
+    frags_global(vf, Vb, ld, k0, T, lane);
+    f32x16 dK[2], dV[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dK[0][i] = 0.f; dK[1][i] = 0.f; dV[0][i] = 0.f; dV[1][i] = 0.f; }
+    const float sc = p.scale * LOG2E;
+    const uint32_t key = p.drop ? dg_site_key_dev(p.rng, p.site) : 0u;
+    const float* lse = p.lse_r + bh * T;
+    const float* dlt = p.delta_r + bh * T;
+
+    u32x4 rq[4], rg[4];
+    tile_load(rq, Qb, ld, k0, T, lane);
+    tile_load(rg, dOb, C, k0, T, lane);
+    for (int qt = kb; qt < p.nblk; ++qt) {
+        tile_store<false>(imgQ, rq, lane);
+        tile_store<true>(imgQt, rq, lane);
+        tile_store<false>(imgG, rg, lane);
+        tile_store<true>(imgGt, rg, lane);
+        if (qt + 1 < p.nblk) {
+            tile_load(rq, Qb, ld, (qt + 1) * TILE, T, lane);
+            tile_load(rg, dOb, C, (qt + 1) * TILE, T, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x16 S, dP;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgQ, ks, lane), kf[ks], S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgG, ks, lane), vf[ks], dP, 0, 0, 0);
+        }
+        const int q0 = qt * TILE;
+        f32x16 Pd;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // rows q0 + 8g + 4hh + 0..3
+            const int qr = q0 + 8 * g + 4 * hh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g + j;
+                const int qi = qr + j;
+                const bool ok = qi < T;
+                const float L2 = ok ? lse[qi] * LOG2E : 0.f;
+                const float dl = ok ? dlt[qi] : 0.f;
+                float pr = exp2f(S[r] * sc - L2);
+                if ((qt == kb && kj > qi) || !ok) pr = 0.f;
+                float keepf = 1.f;
+                if (p.drop) keepf = dg_keep(key, (uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T + kj), p.thr) ? p.inv_keep : 0.f;
+                Pd[r] = pr * keepf;
+                S[r] = pr * (dP[r] * keepf - dl);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 pf = pack8(Pd, s), df = pack8(S, s);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag_tr(imgGt, dt, s, lane), dV[dt], 0, 0, 0);
+                dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, frag_tr(imgQt, dt, s, lane), dK[dt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    bf16_t* dKb = p.dqkv + (int64_t)b * T * ld + C + h * HD;
+    store_N_acc(imgQ, dK, p.scale, dKb, ld, k0, T, lane);
+    __builtin_amdgcn_wave_barrier();
+    store_N_acc(imgQ, dV, 1.f, dKb + C, ld, k0, T, lane);
+}
+
+// =============================================================================================
+bool dg_attn_mfma_supported(int B, int T, int NH, int H) {
+    return H == HD && B > 0 && T > 0 && NH > 0 && (int64_t)B * NH * T * T < ((int64_t)1 << 32);
+}
+
+static void fill(AttnP& p, int B, int T, int NH, float scale, float dp, const uint32_t* rng, uint32_t site) {
+    p.B = B; p.T = T; p.NH = NH; p.nblk = (T + TILE - 1) / TILE;
+    p.n_items = (int64_t)B * NH * p.nblk;
+    p.scale = scale;
+    p.drop = (dp > 0.f && rng) ? 1 : 0;
+    p.inv_keep = 1.f / (1.f - dp);
+    p.thr = dg_drop_threshold(dp);
+    p.rng = rng; p.site = site;
+}
+
+int dg_attn_fwd_mfma(const void* qkv, void* out, float* lse, int B, int T, int NH, int H, float scale, float dp,
+                     const uint32_t* rng, uint32_t site, hipStream_t s) {
+    if (dp < 0.f || dp >= 1.f || !dg_aligned16(qkv) || !dg_aligned16(out)) return DG_ERR_ARG;
+    AttnP p = {};
+    fill(p, B, T, NH, scale, dp, rng, site);
+    p.qkv = (const bf16_t*)qkv; p.out_w = (bf16_t*)out; p.lse = lse;
+    dim3 grid((unsigned)((p.n_items + 3) / 4)), block(256);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, grid, block, 4 * WAVE_LDS_FWD, s, p);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
+                     int B, int T, int NH, int H, float scale, float dp, const uint32_t* rng, uint32_t site, hipStream_t s) {
+    if (dp < 0.f || dp >= 1.f || !dg_aligned16(qkv) || !dg_aligned16(out) || !dg_aligned16(dout) || !dg_aligned16(dqkv)) return DG_ERR_ARG;
+    AttnP p = {};
+    fill(p, B, T, NH, scale, dp, rng, site);
+    p.qkv = (const bf16_t*)qkv; p.out = (const bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv;
+    p.lse_r = lse; p.delta = delta; p.delta_r = delta;
+    const int64_t n = (int64_t)B * T * NH;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.out, p.dout, delta, B, T, NH);
+    DG_LAUNCH_CHECK();
+    dim3 grid((unsigned)((p.n_items + 3) / 4)), block(256);
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, block, 4 * WAVE_LDS_DQ, s, p);
+    DG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, block, 4 * WAVE_LDS_DKV, s, p);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
