@@ -18,7 +18,8 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
-OBJDIR = os.path.join(PKG, "build")
+# objects live outside the tree: only the linked .so has to travel to the GPU box
+OBJDIR = os.environ.get("DRAKEGPT_OBJDIR", os.path.join(os.environ.get("TMPDIR", "/tmp"), f"drakegpt_amd_build_{os.getuid()}"))
 LIB = os.path.join(LIBDIR, "libdrakegpt_hip.so")
 ARCH = "gfx950"
 

@@ -18,6 +18,8 @@
 
 #define BM 128
 #define BN 128
+#define EPI_PITCH 68                         // floats per staged row: 64 + 4 (rows r, r+4 land 16 banks apart)
+#define NT_LDS_BYTES (4 * 64 * EPI_PITCH * 4)  // 69632: four 64x68 fp32 staging slices >= the 4 x 16 KB operand buffers
 
 // ---------------------------------------------------------------------------------------------
 template <typename T> struct MmaTraits;
@@ -53,13 +55,15 @@ struct NtParams {
     float inv_keep; uint32_t thr; int drop;
     const uint32_t* rng_state; uint32_t site;
     int tiles_n, n_tiles;
+    int vec_ok;
 };
 
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
     constexpr int EPC = MmaTraits<T>::EPC;
     constexpr int BK = 8 * EPC;                      // elements of K per step (128 bytes)
-    __shared__ __attribute__((aligned(16))) char lds[2][2][BM * 128];   // [buf][A|B]
+    __shared__ __attribute__((aligned(16))) char lds_raw[NT_LDS_BYTES];   // operands [buf][A|B][16 KB]; the epilogue staging reuses it
+    char (*lds)[2][BM * 128] = reinterpret_cast<char (*)[2][BM * 128]>(lds_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -124,34 +128,73 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
         __syncthreads();
     }
 
-    // epilogue.  C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+    // epilogue: each wave parks its 64x64 fp32 accumulator tile in a private LDS slice (the operand
+    // buffers are free after the last barrier) and reads it back by rows, so every lane handles 4
+    // consecutive columns and the global stores are whole 128/256-byte row segments instead of the
+    // MFMA C/D map's 2/4-byte scatter (col = lane&15, row = (lane>>4)*4 + reg).
+    float* stage = (float*)lds_raw + wave * (64 * EPI_PITCH);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(i * 16 + fg * 4 + r) * EPI_PITCH + j * 16 + fr] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
     uint32_t key = 0;
     if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
     TO* Cp = (TO*)p.C;
+    const int ch = lane & 15;
+    const int col = n0 + wn * 64 + ch * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn * 64 + j * 16 + fr;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+        for (int e = 0; e < 4; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
+    }
+    const bool full = p.vec_ok && (col + 3 < p.N);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int lrow = it * 4 + (lane >> 4);
+        const int row = m0 + wm * 64 + lrow;
+        if (row >= p.M || col >= p.N) continue;
+        f32x4 v = *(const f32x4*)(&stage[lrow * EPI_PITCH + ch * 4]);
+        v += bv;
+        if (p.relu) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.relu_mask) {
+            const T* mp = (const T*)p.relu_mask + (int64_t)row * p.ldmask + col;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + fg * 4 + r;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (p.relu_mask) {
-                    float mk = to_f32<T>(((const T*)p.relu_mask)[(int64_t)row * p.ldmask + col]);
-                    v = mk > 0.f ? v : 0.f;
-                }
-                if (p.drop) {
-                    uint32_t e = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
-                    v = dg_keep(key, e, p.thr) ? v * p.inv_keep : 0.f;
-                }
-                if (p.residual) v += p.residual[(int64_t)row * p.ldr + col];
-                Cp[(int64_t)row * p.ldc + col] = from_f32<TO>(v);
+            for (int e = 0; e < 4; ++e)
+                if (col + e < p.N) v[e] = to_f32<T>(mp[e]) > 0.f ? v[e] : 0.f;
+        }
+        if (p.drop) {
+            const uint32_t eb = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = dg_keep(key, eb + e, p.thr) ? v[e] * p.inv_keep : 0.f;
+        }
+        if (p.residual) {
+            const float* rp = p.residual + (int64_t)row * p.ldr + col;
+            if (full) v += *(const f32x4*)rp;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < p.N) v[e] += rp[e];
             }
+        }
+        TO* cp = Cp + (int64_t)row * p.ldc + col;
+        if (full) {
+            if (sizeof(TO) == 4) *(f32x4*)cp = v;
+            else {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+                *(bf16x4*)cp = o;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < p.N) cp[e] = from_f32<TO>(v[e]);
         }
     }
 }
@@ -178,6 +221,9 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
     p.inv_keep = 1.f / (1.f - a->dropout_p);
     p.thr = dg_drop_threshold(a->dropout_p);
     p.rng_state = a->rng_state; p.site = a->site;
+    const int osz = a->out_dtype == DG_BF16 ? 2 : 4;
+    p.vec_ok = (a->ldc % 4 == 0) && ((((uintptr_t)a->C) % (4 * osz)) == 0) &&
+               (!a->residual || ((a->ldr % 4 == 0) && dg_aligned16(a->residual)));
     const int tiles_m = (a->M + BM - 1) / BM;
     p.tiles_n = (a->N + BN - 1) / BN;
     p.n_tiles = tiles_m * p.tiles_n;
