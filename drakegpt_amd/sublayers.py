@@ -9,7 +9,7 @@ Weight gradients are emitted as partial sums through a `sink` (see GradSink belo
 operands (bf16 copies / transposes) come from a `weights` provider, so that the engine can keep
 flat, persistent buffers while the autograd path allocates on the fly.
 
-Reference call sites restated here (all relative to /root/reference/):
+Reference call sites restated here (paths relative to the reference repository root):
   attention sub-layer  x + dropout(proj(cat_h softmax(mask(q k^T * s)) v))   src/model_component.py:378-407,436-455,505
   feed-forward         x + dropout(W2 relu(W1 ln(x) + b1) + b2)              src/model_component.py:320-325,506
   embedding            tok[idx] + pos[arange(T)]                             src/model.py:595-597

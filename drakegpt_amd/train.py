@@ -1,0 +1,188 @@
+"""Training harness -- the reference's src/train.py on the HIP path.
+
+    python -m drakegpt_amd.train --model TransformerLM --scale --data path/to/text.txt [--iters N]
+    python -m torch.distributed.run --nproc-per-node 8 -m drakegpt_amd.train --model TransformerLM --scale ...
+
+Kept from the reference (src/train.py): build_model's per-model constructor arguments (:31-57),
+evaluate_loss (eval mode, mean of eval_iters batch losses on train and val, :61-75), get_model_path
+naming (:77-83), AdamW(lr=base_lr, betas) (:121), CyclicLR(base_lr, max_lr, step_size_up=5,
+triangular) stepped once per evaluation (:122-126,162), seed 42 (:86), the step order
+forward -> zero_grad -> backward -> step (:146-151), the final 100-token sample (:174-178) and the
+state_dict checkpoint (:181-183).  Differences, on purpose: the selected preset
+is used everywhere (batch shape and learning rates too), flags are real booleans, wandb is replaced
+by JSON lines on stdout, and without --data a synthetic uniform char corpus stands in for the
+Kaggle download.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import time
+from typing import Optional
+
+import torch
+
+from . import dist as ddist
+from .config import DRAKE_VOCAB_SIZE, PARAMS, PRESETS, SCALE_PARAMS, TRAIN
+from .model import MODEL_CLASSES, model_params
+from .preprocessing import draw_offsets, encode_text, split_train_val
+
+
+def build_model(model_name: str, scale: bool, params: dict, scale_params: dict, vocab_size: int, device, precision: str = "fp32"):
+    """ref: src/train.py:16-59 -- returns (model, model_config, params)."""
+    if scale:
+        params = scale_params
+    if model_name not in MODEL_CLASSES:
+        raise KeyError(f"unknown model {model_name!r}; choose from {list(MODEL_CLASSES)}")
+    C, T = params["embedding_dim"], params["context_length"]
+    cfg = {
+        "BigramLM": dict(vocab_size=vocab_size),
+        "SingleHeadAttentionLM": dict(vocab_size=vocab_size, embedding_dim=C, context_length=T, head_size=params["head_size"]),
+        "MultiHeadAttentionLM": dict(vocab_size=vocab_size, embedding_dim=C, context_length=T, head_size=params["head_size"],
+                                     num_heads=params["num_heads"]),
+        "BlocksLM": dict(vocab_size=vocab_size, embedding_dim=C, context_length=T, num_heads=params["num_heads"],
+                         num_layers=params["num_layers"]),
+        "ResidualBlocksLM": dict(vocab_size=vocab_size, embedding_dim=C, context_length=T, num_heads=params["num_heads"],
+                                 num_layers=params["num_layers"]),
+        "TransformerLM": dict(vocab_size=vocab_size, embedding_dim=C, context_length=T, num_heads=params["num_heads"],
+                              num_layers=params["num_layers"], dropout=params["dropout"]),
+    }[model_name]
+    model = MODEL_CLASSES[model_name](**cfg, precision=precision).to(device)
+    return model, cfg, params
+
+
+def get_model_path(dir, model_name: str, scale: bool) -> str:
+    """ref: src/train.py:77-83"""
+    return os.path.join(dir, f"{model_name}_scaled.pt" if scale else f"{model_name}.pt")
+
+
+def cyclic_lr(step_count: int, base_lr: float, max_lr: float, step_size_up: int = 5) -> float:
+    """torch CyclicLR(mode='triangular', cycle_momentum=False) after `step_count` scheduler steps"""
+    total = 2.0 * step_size_up
+    cycle = math.floor(1 + step_count / total)
+    x = 1.0 + step_count / total - cycle
+    ratio = step_size_up / total
+    scale = x / ratio if x <= ratio else (x - 1) / (ratio - 1)
+    return base_lr + (max_lr - base_lr) * scale
+
+
+@torch.no_grad()
+def evaluate_loss(train_data, val_data, model, eval_iters, context_length, batch_size, device, engine=None, generator=None):
+    """ref: src/train.py:61-75.  `model` must be in eval mode; batches are drawn as get_batch does."""
+    from . import ops
+    out = {}
+    for name, data in (("train", train_data), ("val", val_data)):
+        losses = torch.zeros(eval_iters)
+        for it in range(eval_iters):
+            ix = draw_offsets(len(data), context_length, batch_size, generator).to(device)
+            x, y = ops.batch_gather(data, ix, context_length)
+            loss = engine.eval_loss(x, y) if engine is not None else model(x, y)[1]
+            losses[it] = loss.item()
+        out[name] = losses.mean()
+    return out
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Train a DrakeGPT language model on MI355X")
+    ap.add_argument("--model", default="TransformerLM", choices=list(MODEL_CLASSES))
+    ap.add_argument("--scale", action="store_true", help="use SCALE_PARAMS (ref: --scale True)")
+    ap.add_argument("--preset", default=None, choices=list(PRESETS), help="overrides --scale")
+    ap.add_argument("--no-save", action="store_true")
+    ap.add_argument("--data", default=None, help="UTF-8 text file (the reference's data/Drake_lyrics.txt)")
+    ap.add_argument("--iters", type=int, default=TRAIN["iters"])
+    ap.add_argument("--eval-interval", type=int, default=TRAIN["eval_interval"])
+    ap.add_argument("--eval-iters", type=int, default=TRAIN["eval_iters"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--model-dir", default="model")
+    ap.add_argument("--sample", type=int, default=100)
+    args = ap.parse_args(argv)
+
+    torch.manual_seed(42)
+    if not torch.cuda.is_available():
+        raise SystemExit("drakegpt_amd.train needs an MI355X (no CPU path)")
+    rank, local_rank, world = ddist.env_world()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = ddist.init("nccl", device)
+
+    if args.data:
+        with open(args.data, "r", encoding="utf-8") as f:
+            text = f.read()
+        data, decode, vocab_size = encode_text(text)
+    else:
+        vocab_size = DRAKE_VOCAB_SIZE
+        data = torch.randint(0, vocab_size, (1_000_000,), generator=torch.Generator().manual_seed(42))
+        decode = lambda ids: " ".join(str(i) for i in ids)      # noqa: E731
+    train_data, val_data = split_train_val(data)
+    train_dev, val_dev = train_data.to(device), val_data.to(device)
+
+    params = PRESETS[args.preset] if args.preset else (SCALE_PARAMS if args.scale else PARAMS)
+    vocab_size = params.get("vocab_size", vocab_size)
+    model, model_config, params = build_model(args.model, False, params, params, vocab_size, device, args.precision)
+    if rank == 0:
+        print(f"Selected {args.model} model for training. Model has {model_params(params, args.model, vocab_size)} parameters "
+              f"(reference estimate; actual {sum(p.numel() for p in model.parameters())}).")
+    B, T = params["batch_size"], params["context_length"]
+    base_lr, max_lr = params["base_lr"], params["max_lr"]
+
+    engine = None
+    if args.model == "TransformerLM":
+        from .engine import TrainEngine
+        engine = TrainEngine(model, B, T, lr=base_lr, betas=params["betas"], seed=42, rank=rank, world_size=world, process_group=pg)
+        engine.set_corpus(train_dev)
+    else:
+        if world > 1:
+            raise SystemExit("data-parallel training is implemented for TransformerLM (the engine path)")
+        from .optim import AdamW
+        optimizer = AdamW(model.parameters(), lr=base_lr, betas=params["betas"])
+
+    model.train()
+    sched_steps = 0
+    gen = None                       # the global CPU generator, as the reference uses
+    t0 = time.perf_counter()
+    for it in range(args.iters):
+        ix = draw_offsets(len(train_data), T, B * world, gen)
+        ix = ddist.shard_rows(ix, rank, world).to(device, non_blocking=True)
+        if engine is not None:
+            engine.set_offsets(ix)
+            engine.step()
+        else:
+            from . import ops
+            x, y = ops.batch_gather(train_dev, ix, T)
+            logits, loss = model(x, y)
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+        if (it + 1) % args.eval_interval == 0:
+            model.eval()
+            losses = evaluate_loss(train_dev, val_dev, model, args.eval_iters, T, B, device, engine=engine)
+            sched_steps += 1
+            lr = cyclic_lr(sched_steps, base_lr, max_lr)
+            if engine is not None:
+                engine.set_lr(lr)
+            else:
+                for g in optimizer.param_groups:
+                    g["lr"] = lr
+            if rank == 0:
+                el = time.perf_counter() - t0
+                print(json.dumps({"step": it + 1, "train_loss": float(losses["train"]), "val_loss": float(losses["val"]), "lr": lr,
+                                  "tokens_per_s": (it + 1) * B * T * world / el}), flush=True)
+            model.train()
+
+    model.eval()
+    if rank == 0:
+        idx = torch.zeros((1, 1), dtype=torch.long, device=device)
+        print(decode(model.generate(idx, max_new_tokens=args.sample)[0].tolist()))
+        if not args.no_save:
+            os.makedirs(args.model_dir, exist_ok=True)
+            path = get_model_path(args.model_dir, args.model, args.scale)
+            torch.save({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, path)
+            print(f"saved {path}")
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
