@@ -89,3 +89,36 @@ def test_corpus_gather_path(dev, golden_dir):
     gen = torch.Generator().manual_seed(5)
     x, y = R.get_batch(data, 8, 32, gen)
     assert torch.equal(eng.x.cpu(), x) and torch.equal(eng.y.cpu(), y)
+
+
+@pytest.mark.parametrize("name", ["BigramLM", "TransformerLM"])
+def test_module_path_with_hip_adamw_matches_reference_trajectory(dev, golden_dir, name):
+    """the drop-in loop of src/train.py:146-151 (forward, zero_grad, backward, step) on the autograd path"""
+    import drakegpt_amd as D
+    from drakegpt_amd.optim import AdamW
+    fix = torch.load(os.path.join(golden_dir, f"traj5_{name}.pt"), weights_only=True)
+    m = D.BigramLM(V) if name == "BigramLM" else D.TransformerLM(V, 32, 8, 4, 3, 0.0)
+    m.load_state_dict(fix["init"])
+    m = m.to(dev).train()
+    opt = AdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.95))
+    for it in range(5):
+        logits, loss = m(fix["x"][it].to(dev), fix["y"][it].to(dev))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        assert abs(loss.item() - fix["losses"][it].item()) < 2e-4 * abs(fix["losses"][it].item())
+    sd = m.state_dict()
+    for k, v in fix["final"].items():
+        assert (sd[k].cpu() - v).abs().max().item() < 2e-5, k
+
+
+def test_train_harness_smoke(dev, tmp_path, capsys):
+    from drakegpt_amd import train
+    train.main(["--model", "TransformerLM", "--iters", "6", "--eval-interval", "3", "--eval-iters", "2", "--precision", "fp32",
+                "--model-dir", str(tmp_path), "--sample", "5"])
+    out = capsys.readouterr().out
+    assert '"val_loss"' in out and "saved" in out
+    sd = torch.load(tmp_path / "TransformerLM.pt", weights_only=True)
+    assert "blocks.2.sa_head.heads.3.tril" in sd and sd["ln_f.weight"].eq(1).all()
+    train.main(["--model", "BlocksLM", "--iters", "4", "--eval-interval", "2", "--eval-iters", "2", "--precision", "fp32", "--no-save",
+                "--sample", "3"])
