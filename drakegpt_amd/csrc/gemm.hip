@@ -15,6 +15,7 @@
 // (T1).  bf16: v_mfma_f32_16x16x32_bf16; f32 (parity mode): v_mfma_f32_16x16x4_f32, which is
 // bit-exact fp32 FMA accumulation (guide section 3, "FP32-input MFMA").
 #include "common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -55,8 +56,79 @@ struct NtParams {
     float inv_keep; uint32_t thr; int drop;
     const uint32_t* rng_state; uint32_t site;
     int tiles_n, n_tiles;
-    int vec_ok;
+    int vec_ok, mask_vec_ok;
 };
+
+// Row-wise epilogue over a wave's staged fp32 tile (ROWS x 64, pitch EPI_PITCH floats): every lane
+// handles 4 consecutive columns, so the global stores are whole 128/256-byte row segments instead of
+// the MFMA C/D map's 2/4-byte scatter.  Order: +bias, ReLU, ReLU-mask, dropout, +residual, cast.
+template <typename T, typename TO, int ROWS>
+__device__ __forceinline__ void nt_epilogue(const float* stage, int row_base, int col_base, const NtParams& p, int lane) {
+    uint32_t key = 0;
+    if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
+    TO* Cp = (TO*)p.C;
+    const int ch = lane & 15;
+    const int col = col_base + ch * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
+    }
+    const bool full = p.vec_ok && (col + 3 < p.N);
+#pragma unroll 4
+    for (int it = 0; it < ROWS / 4; ++it) {
+        const int lrow = it * 4 + (lane >> 4);
+        const int row = row_base + lrow;
+        if (row >= p.M || col >= p.N) continue;
+        f32x4 v = *(const f32x4*)(&stage[lrow * EPI_PITCH + ch * 4]);
+        v += bv;
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.relu_mask) {
+            const T* mp = (const T*)p.relu_mask + (int64_t)row * p.ldmask + col;
+            if (full && p.mask_vec_ok) {
+                typedef T TV4 __attribute__((ext_vector_type(4)));
+                const TV4 mk = *(const TV4*)mp;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = to_f32<T>(mk[e]) > 0.f ? v[e] : 0.f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < p.N) v[e] = to_f32<T>(mp[e]) > 0.f ? v[e] : 0.f;
+            }
+        }
+        if (p.drop) {
+            const uint32_t eb = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = dg_keep(key, eb + e, p.thr) ? v[e] * p.inv_keep : 0.f;
+        }
+        if (p.residual) {
+            const float* rp = p.residual + (int64_t)row * p.ldr + col;
+            if (full) v += *(const f32x4*)rp;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < p.N) v[e] += rp[e];
+            }
+        }
+        TO* cp = Cp + (int64_t)row * p.ldc + col;
+        if (full) {
+            if (sizeof(TO) == 4) *(f32x4*)cp = v;
+            else {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+                *(bf16x4*)cp = o;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < p.N) cp[e] = from_f32<TO>(v[e]);
+        }
+    }
+}
 
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
@@ -129,9 +201,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
     }
 
     // epilogue: each wave parks its 64x64 fp32 accumulator tile in a private LDS slice (the operand
-    // buffers are free after the last barrier) and reads it back by rows, so every lane handles 4
-    // consecutive columns and the global stores are whole 128/256-byte row segments instead of the
-    // MFMA C/D map's 2/4-byte scatter (col = lane&15, row = (lane>>4)*4 + reg).
+    // buffers are free after the last barrier) and reads it back by rows (nt_epilogue).
     float* stage = (float*)lds_raw + wave * (64 * EPI_PITCH);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -140,63 +210,101 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) stage[(i * 16 + fg * 4 + r) * EPI_PITCH + j * 16 + fr] = acc[i][j][r];
     __builtin_amdgcn_wave_barrier();
-    uint32_t key = 0;
-    if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
-    TO* Cp = (TO*)p.C;
-    const int ch = lane & 15;
-    const int col = n0 + wn * 64 + ch * 4;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
+    nt_epilogue<T, TO, 64>(stage, m0 + wm * 64, n0 + wn * 64, p, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 NT GEMM with a 4-stage global_load_lds pipeline (K % 64 == 0).  The register-staged kernel
+// above keeps one K step of loads in flight, which leaves the K = 384..1536 shapes of the training
+// step latency-bound; here LDS-DMA writes the XOR-swizzled image directly (linear destination,
+// permuted per-lane SOURCE chunk -- guide rule 21), three stages stay in flight across the single
+// raw s_barrier of a K step, and waits are counted (never vmcnt(0) inside the loop).
+// 512 threads = 8 waves (4 x 2) of 32 x 64, two waves per SIMD; 128 KB LDS, one workgroup per CU.
+#define GL_NST 4
+#define GL_STAGE 32768
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename TO>
+__global__ __launch_bounds__(512) void gemm_nt_glds_kernel(NtParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = dg_xcd_remap(blockIdx.x, p.n_tiles);
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int nk = p.K / 64;
+
+    // LDS-DMA pieces: one wave instruction = 1 KB = 8 rows x 128 B.  Lane (prow, slot) lands on
+    // row*128 + slot*16, so it must fetch chunk = slot ^ (row & 7) = slot ^ prow of its row.
+    const int prow = lane >> 3, slot = lane & 7;
+    const int chunk = slot ^ prow;
+    const char* srcA[2];
+    const char* srcB[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
+    for (int i = 0; i < 2; ++i) {
+        const int row = (2 * wave + i) * 8 + prow;
+        int gm = m0 + row; if (gm > p.M - 1) gm = p.M - 1;      // rows past the edge: any finite data,
+        int gn = n0 + row; if (gn > p.N - 1) gn = p.N - 1;      // they only feed outputs that are not stored
+        srcA[i] = p.A + (int64_t)gm * p.lda_b + chunk * 16;
+        srcB[i] = p.B + (int64_t)gn * p.ldb_b + chunk * 16;
     }
-    const bool full = p.vec_ok && (col + 3 < p.N);
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int lrow = it * 4 + (lane >> 4);
-        const int row = m0 + wm * 64 + lrow;
-        if (row >= p.M || col >= p.N) continue;
-        f32x4 v = *(const f32x4*)(&stage[lrow * EPI_PITCH + ch * 4]);
-        v += bv;
-        if (p.relu) {
+    auto issue = [&](int kt) {
+        char* base = lds + (kt & (GL_NST - 1)) * GL_STAGE + (2 * wave) * 1024;
+        const int64_t koff = (int64_t)kt * 128;
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[0] + koff), (lptr_t)(base), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[1] + koff), (lptr_t)(base + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcB[0] + koff), (lptr_t)(base + 16384), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcB[1] + koff), (lptr_t)(base + 16384 + 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[2][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (p.relu_mask) {
-            const T* mp = (const T*)p.relu_mask + (int64_t)row * p.ldmask + col;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (col + e < p.N) v[e] = to_f32<T>(mp[e]) > 0.f ? v[e] : 0.f;
-        }
-        if (p.drop) {
-            const uint32_t eb = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int npre = nk < GL_NST - 1 ? nk : GL_NST - 1;
+    for (int s = 0; s < npre; ++s) issue(s);
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        int issued = kt + GL_NST - 1; if (issued > nk) issued = nk;
+        const int ahead = issued - (kt + 1);                 // stages that may stay in flight
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // stage kt landed for every wave; stage kt-1 fully read
+        if (kt + GL_NST - 1 < nk) issue(kt + GL_NST - 1);    // refills the buffer read in iteration kt-1
+        const char* bufA = lds + (kt & (GL_NST - 1)) * GL_STAGE;
+        const char* bufB = bufA + 16384;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = dg_keep(key, eb + e, p.thr) ? v[e] * p.inv_keep : 0.f;
-        }
-        if (p.residual) {
-            const float* rp = p.residual + (int64_t)row * p.ldr + col;
-            if (full) v += *(const f32x4*)rp;
-            else {
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 fa[2], fb[4];
+            const int ck = ks * 4 + fg;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < p.N) v[e] += rp[e];
-            }
-        }
-        TO* cp = Cp + (int64_t)row * p.ldc + col;
-        if (full) {
-            if (sizeof(TO) == 4) *(f32x4*)cp = v;
-            else {
-                bf16x4 o;
+            for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(bufA + nt_lds_off(wm * 32 + i * 16 + fr, ck));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-                *(bf16x4*)cp = o;
-            }
-        } else {
+            for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(bufB + nt_lds_off(wn * 64 + j * 16 + fr, ck));
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (col + e < p.N) cp[e] = from_f32<TO>(v[e]);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16<bf16_t>(fa[i], fb[j], acc[i][j]);
         }
     }
+    __syncthreads();                                         // every wave is done with the operand buffers
+    float* stage = (float*)lds + wave * (32 * EPI_PITCH);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stage[(i * 16 + fg * 4 + r) * EPI_PITCH + j * 16 + fr] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+    nt_epilogue<bf16_t, TO, 32>(stage, m0 + wm * 32, n0 + wn * 64, p, lane);
+}
+
+static bool dg_nt_force_regstage() {          // A/B switch for benchmarking: DG_GEMM_REGSTAGE=1
+    static const bool v = [] { const char* e = getenv("DG_GEMM_REGSTAGE"); return e && e[0] == '1'; }();
+    return v;
 }
 
 extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
@@ -224,12 +332,16 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
     const int osz = a->out_dtype == DG_BF16 ? 2 : 4;
     p.vec_ok = (a->ldc % 4 == 0) && ((((uintptr_t)a->C) % (4 * osz)) == 0) &&
                (!a->residual || ((a->ldr % 4 == 0) && dg_aligned16(a->residual)));
+    p.mask_vec_ok = a->relu_mask && (a->ldmask % 4 == 0) && ((((uintptr_t)a->relu_mask) % (4 * esz)) == 0);
     const int tiles_m = (a->M + BM - 1) / BM;
     p.tiles_n = (a->N + BN - 1) / BN;
     p.n_tiles = tiles_m * p.tiles_n;
     dim3 grid(p.n_tiles), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (a->in_dtype == DG_BF16 && a->out_dtype == DG_BF16)
+    if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && !dg_nt_force_regstage()) {
+        if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16_t>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_nt_glds_kernel<float>), grid, dim3(512), 0, s, p);
+    } else if (a->in_dtype == DG_BF16 && a->out_dtype == DG_BF16)
         hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, block, 0, s, p);
     else if (a->in_dtype == DG_BF16)
         hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, block, 0, s, p);

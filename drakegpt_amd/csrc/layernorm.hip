@@ -85,14 +85,15 @@ extern "C" int dg_layernorm_fwd(const float* x, const float* gamma, const float*
 //   dx = rstd * (g - mean(g) - xhat*mean(g*xhat)) (+ dresid).
 // dgamma/dbeta column partials accumulate in registers per lane, are combined across the 4 waves
 // through LDS and written as partial #blockIdx.x.
-template <bool VEC, int LN_MAXV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <bool VEC, int LN_MAXV, int NTHREADS>
+__global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                               const float* __restrict__ gamma, const float* __restrict__ mean,
                               const float* __restrict__ rstd, const float* __restrict__ dresid,
                               float* __restrict__ dx, float* __restrict__ dgamma_part,
                               float* __restrict__ dbeta_part, int64_t part_stride,
                               int M, int C, int rows_per) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][4][C] when VEC, else unused layout below
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][NW][C]
+    constexpr int NW = NTHREADS / 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m_begin = blockIdx.x * rows_per;
     int m_end = m_begin + rows_per; if (m_end > M) m_end = M;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             dg[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
             db[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        for (int row = m_begin + w; row < m_end; row += 4) {
+        for (int row = m_begin + w; row < m_end; row += NW) {
             const float mu = mean[row], rs = rstd[row];
             const f32x4* dyr = (const f32x4*)(dy + (int64_t)row * C);
             const f32x4* xr = (const f32x4*)(x + (int64_t)row * C);
@@ -144,9 +145,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 }
             }
         }
-        // combine the 4 waves' column partials
-        float* lg = lds;               // [4][C]
-        float* lb = lds + 4 * C;       // [4][C]
+        // combine the waves' column partials
+        float* lg = lds;               // [NW][C]
+        float* lb = lds + NW * C;      // [NW][C]
 #pragma unroll
         for (int k = 0; k < LN_MAXV; ++k) {
             int i = lane + k * 64;
@@ -154,16 +155,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            float a = (lg[c] + lg[C + c]) + (lg[2 * C + c] + lg[3 * C + c]);
-            float b = (lb[c] + lb[C + c]) + (lb[2 * C + c] + lb[3 * C + c]);
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) { a += lg[k * C + c]; b += lb[k * C + c]; }
             dgamma_part[(int64_t)blockIdx.x * part_stride + c] = a;
             dbeta_part[(int64_t)blockIdx.x * part_stride + c] = b;
         }
     } else {
-        // generic path: any C; column partials accumulate directly in LDS [2][4][C] per wave
-        float* lg = lds; float* lb = lds + 4 * C;
+        // generic path: any C; column partials accumulate directly in LDS [2][NW][C] per wave
+        float* lg = lds; float* lb = lds + NW * C;
         for (int c = lane; c < C; c += 64) { lg[w * C + c] = 0.f; lb[w * C + c] = 0.f; }
-        for (int row = m_begin + w; row < m_end; row += 4) {
+        for (int row = m_begin + w; row < m_end; row += NW) {
             const float mu = mean[row], rs = rstd[row];
             const float* dyr = dy + (int64_t)row * C;
             const float* xr = x + (int64_t)row * C;
@@ -184,8 +186,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            float a = (lg[c] + lg[C + c]) + (lg[2 * C + c] + lg[3 * C + c]);
-            float b = (lb[c] + lb[C + c]) + (lb[2 * C + c] + lb[3 * C + c]);
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) { a += lg[k * C + c]; b += lb[k * C + c]; }
             dgamma_part[(int64_t)blockIdx.x * part_stride + c] = a;
             dbeta_part[(int64_t)blockIdx.x * part_stride + c] = b;
         }
@@ -198,21 +201,23 @@ extern "C" int dg_layernorm_bwd(const float* dy, const float* x, const float* ga
                                 int M, int C, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma_part || !dbeta_part) return DG_ERR_ARG;
     if (M <= 0 || C <= 0 || n_partials <= 0 || part_stride < C) return DG_ERR_ARG;
-    size_t lds_bytes = (size_t)8 * C * sizeof(float);
+    // more waves per workgroup = more rows in flight per partial (HBM-bound: needs the occupancy)
+    const int nthreads = C <= 512 ? 1024 : (C <= 1024 ? 512 : 256);
+    size_t lds_bytes = (size_t)2 * (nthreads / 64) * C * sizeof(float);
     bool vec = (C % 4 == 0) && (C <= 64 * 4 * LN_MAXV_CAP) && dg_aligned16(dy) && dg_aligned16(x) && dg_aligned16(gamma) &&
                dg_aligned16(dx) && (!dresid || dg_aligned16(dresid));
     int rows_per = (M + n_partials - 1) / n_partials;
-    dim3 grid(n_partials), block(256);
+    dim3 grid(n_partials), block(nthreads);
     hipStream_t s = (hipStream_t)stream;
     if (lds_bytes > 64 * 1024) return DG_ERR_ARG;   // C <= 2048 on either path
     const int nk = (C / 4 + 63) / 64;
-#define LAUNCH(V, K) hipLaunchKernelGGL((ln_bwd_kernel<V, K>), grid, block, lds_bytes, s, dy, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part, part_stride, M, C, rows_per)
-    if (!vec) LAUNCH(false, 1);
-    else if (nk <= 1) LAUNCH(true, 1);
-    else if (nk == 2) LAUNCH(true, 2);
-    else if (nk == 3) LAUNCH(true, 3);
-    else if (nk == 4) LAUNCH(true, 4);
-    else LAUNCH(true, 8);
+#define LAUNCH(V, K, NT) hipLaunchKernelGGL((ln_bwd_kernel<V, K, NT>), grid, block, lds_bytes, s, dy, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part, part_stride, M, C, rows_per)
+    if (!vec) { if (nthreads == 1024) LAUNCH(false, 1, 1024); else if (nthreads == 512) LAUNCH(false, 1, 512); else LAUNCH(false, 1, 256); }
+    else if (nk <= 1) LAUNCH(true, 1, 1024);
+    else if (nk == 2) LAUNCH(true, 2, 1024);
+    else if (nk == 3) LAUNCH(true, 3, 512);
+    else if (nk == 4) LAUNCH(true, 4, 512);
+    else LAUNCH(true, 8, 256);
 #undef LAUNCH
     DG_LAUNCH_CHECK();
     return DG_OK;
