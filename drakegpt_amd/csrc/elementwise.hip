@@ -214,9 +214,17 @@ __global__ void dropbwd_cast_kernel(const TI* __restrict__ dy, int64_t lddy, TO*
     if (DROP) key = dg_site_key_dev(rng_state, site);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const bool full = (c + 3 < N);
+    const bool vec_in = (lddy % 4 == 0) && ((((uintptr_t)dy) % (4 * sizeof(TI))) == 0);
+    const bool vec_out = g && (ldg % 4 == 0) && ((((uintptr_t)g) % (4 * sizeof(TO))) == 0);
+#pragma unroll 4
     for (int m = m_begin + ty; m < m_end; m += 4) {
         float v[4];
-        if (full) {
+        if (full && vec_in) {
+            typedef TI TI4 __attribute__((ext_vector_type(4)));
+            const TI4 t = *(const TI4*)(dy + (int64_t)m * lddy + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = to_f32<TI>(t[j]);
+        } else if (full) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = to_f32<TI>(dy[(int64_t)m * lddy + c + j]);
         } else {
@@ -231,7 +239,14 @@ __global__ void dropbwd_cast_kernel(const TI* __restrict__ dy, int64_t lddy, TO*
             }
             if (relu_mask && c + j < N) v[j] = relu_mask[(int64_t)m * ldmask + c + j] > 0.f ? v[j] : 0.f;
             acc[j] += v[j];
-            if (g && c + j < N) g[(int64_t)m * ldg + c + j] = from_f32<TO>(v[j]);
+            if (g && !(full && vec_out) && c + j < N) g[(int64_t)m * ldg + c + j] = from_f32<TO>(v[j]);
+        }
+        if (g && full && vec_out) {
+            typedef TO TO4 __attribute__((ext_vector_type(4)));
+            TO4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = from_f32<TO>(v[j]);
+            *(TO4*)(g + (int64_t)m * ldg + c) = o;
         }
     }
     if (part) {

@@ -8,55 +8,83 @@
 // LN_MAXV (template): float4 per lane kept in registers; C <= 256*LN_MAXV on the fast path
 #define LN_MAXV_CAP 8
 
+#define LN_RPW 4      // rows per wave, loaded together: the forward kernel is latency-bound, not byte-bound
 template <typename TO, bool VEC, int LN_MAXV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                               const float* __restrict__ beta, TO* __restrict__ y,
                               float* __restrict__ mean, float* __restrict__ rstd, int M, int C, float eps) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const float* xr = x + (int64_t)row * C;
-    TO* yr = y + (int64_t)row * C;
+    const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * LN_RPW;
+    if (row0 >= M) return;
     const float invC = 1.f / (float)C;
     if (VEC) {
         const int nv = C >> 2;            // float4 count
-        f32x4 v[LN_MAXV];
-        float s = 0.f;
+        f32x4 v[LN_RPW][LN_MAXV];
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
-            int i = lane + k * 64;
-            if (i < nv) { v[k] = ((const f32x4*)xr)[i]; s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]); }
-        }
-        const float mu = wave_sum(s) * invC;
-        float q = 0.f;
+        for (int r = 0; r < LN_RPW; ++r) {
+            const int row = row0 + r < M ? row0 + r : M - 1;
+            const f32x4* xr = (const f32x4*)(x + (int64_t)row * C);
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
-            int i = lane + k * 64;
-            if (i < nv) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { float d = v[k][j] - mu; q += d * d; }
+            for (int k = 0; k < LN_MAXV; ++k) {
+                int i = lane + k * 64;
+                v[r][k] = (i < nv) ? xr[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        const float rs = rsqrtf(wave_sum(q) * invC + eps);
-        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        f32x4 g[LN_MAXV], b[LN_MAXV];
 #pragma unroll
         for (int k = 0; k < LN_MAXV; ++k) {
             int i = lane + k * 64;
-            if (i < nv) {
-                f32x4 g = ((const f32x4*)gamma)[i], b = ((const f32x4*)beta)[i];
+            g[k] = (i < nv) ? ((const f32x4*)gamma)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            b[k] = (i < nv) ? ((const f32x4*)beta)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) yr[i * 4 + j] = from_f32<TO>((v[k][j] - mu) * rs * g[j] + b[j]);
+        for (int r = 0; r < LN_RPW; ++r) {
+            const int row = row0 + r;
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < LN_MAXV; ++k) s += (v[r][k][0] + v[r][k][1]) + (v[r][k][2] + v[r][k][3]);
+            const float mu = wave_sum(s) * invC;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < LN_MAXV; ++k) {
+                int i = lane + k * 64;
+                if (i < nv) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { float d = v[r][k][j] - mu; q += d * d; }
+                }
+            }
+            const float rs = rsqrtf(wave_sum(q) * invC + eps);
+            if (row < M) {
+                if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+                TO* yr = y + (int64_t)row * C;
+#pragma unroll
+                for (int k = 0; k < LN_MAXV; ++k) {
+                    int i = lane + k * 64;
+                    if (i < nv) {
+                        typedef TO TO4 __attribute__((ext_vector_type(4)));
+                        TO4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = from_f32<TO>((v[r][k][j] - mu) * rs * g[k][j] + b[k][j]);
+                        *(TO4*)(yr + i * 4) = o;
+                    }
+                }
             }
         }
     } else {
-        float s = 0.f;
-        for (int i = lane; i < C; i += 64) s += xr[i];
-        const float mu = wave_sum(s) * invC;
-        float q = 0.f;
-        for (int i = lane; i < C; i += 64) { float d = xr[i] - mu; q += d * d; }
-        const float rs = rsqrtf(wave_sum(q) * invC + eps);
-        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-        for (int i = lane; i < C; i += 64) yr[i] = from_f32<TO>((xr[i] - mu) * rs * gamma[i] + beta[i]);
+        for (int r = 0; r < LN_RPW; ++r) {
+            const int row = row0 + r;
+            if (row >= M) break;
+            const float* xr = x + (int64_t)row * C;
+            TO* yr = y + (int64_t)row * C;
+            float s = 0.f;
+            for (int i = lane; i < C; i += 64) s += xr[i];
+            const float mu = wave_sum(s) * invC;
+            float q = 0.f;
+            for (int i = lane; i < C; i += 64) { float d = xr[i] - mu; q += d * d; }
+            const float rs = rsqrtf(wave_sum(q) * invC + eps);
+            if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+            for (int i = lane; i < C; i += 64) yr[i] = from_f32<TO>((xr[i] - mu) * rs * gamma[i] + beta[i]);
+        }
     }
 }
 
@@ -65,7 +93,7 @@ extern "C" int dg_layernorm_fwd(const float* x, const float* gamma, const float*
     if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || C <= 0) return DG_ERR_ARG;
     bool vec = (C % 4 == 0) && (C <= 64 * 4 * LN_MAXV_CAP) && dg_aligned16(x) && dg_aligned16(gamma) && dg_aligned16(beta);
     const int nk = (C / 4 + 63) / 64;      // float4 per lane
-    dim3 grid((M + 3) / 4), block(256);
+    dim3 grid((M + 4 * LN_RPW - 1) / (4 * LN_RPW)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(TO, V, K) hipLaunchKernelGGL((ln_fwd_kernel<TO, V, K>), grid, block, 0, s, x, gamma, beta, (TO*)y, mean, rstd, M, C, eps)
 #define LAUNCH_K(TO) do { if (!vec) LAUNCH(TO, false, 1); else if (nk <= 1) LAUNCH(TO, true, 1); else if (nk == 2) LAUNCH(TO, true, 2); \
