@@ -55,6 +55,7 @@ SIGNATURES = {
     "dg_dropout_bwd_cast": [_vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp, _u32, _vp, _i64, _vp, _i64, _i, _vp],
     "dg_cast": [_vp, _i, _vp, _i, _i64, _vp],
     "dg_transpose_cast": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp],
+    "dg_transpose_cast_batched": [_vp, _i, _i, _i, _vp],
     "dg_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
     "dg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
     "dg_cross_entropy": [_vp, _i64, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _i, _vp],

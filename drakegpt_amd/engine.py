@@ -238,8 +238,9 @@ class TrainEngine:
         self._refresh_transposes()
 
     def _refresh_transposes(self):
-        for W, Wt in self._mats:
-            ops.transpose_cast(W, self.act, ldo=Wt.shape[1], out=Wt)
+        if getattr(self, "_tr_table", None) is None:
+            self._tr_table = ops.make_transpose_table(self._mats, self.dev)
+        ops.transpose_cast_batched(*self._tr_table, self.act)
 
     # -------------------------------------------------------------------------------- programs
     def _layer_params(self, l: int):

@@ -234,6 +234,23 @@ def transpose_cast(W: Tensor, out_dtype: torch.dtype, ldo: Optional[int] = None,
     return out
 
 
+def make_transpose_table(pairs, device) -> tuple:
+    """descriptor table for transpose_cast_batched: pairs = [(W [R,C] fp32, Wt [C, ldo])]"""
+    rows, first = [], 0
+    for W, Wt in pairs:
+        R, Cc = W.shape
+        ldo = Wt.shape[1]
+        tiles_x, tiles_y = (Cc + 63) // 64, (ldo + 63) // 64
+        rows.append([W.data_ptr(), Wt.data_ptr(), _ld(W), ldo, R, Cc, first, tiles_x])
+        first += tiles_x * tiles_y
+    return torch.tensor(rows, dtype=torch.int64, device=device), len(rows), first
+
+
+def transpose_cast_batched(table: Tensor, n_desc: int, total_tiles: int, dtype: torch.dtype) -> None:
+    _chk(table, "table", torch.int64)
+    check(lib.dg_transpose_cast_batched(_p(table), n_desc, total_tiles, dt_code(dtype), _stream()), "dg_transpose_cast_batched")
+
+
 def attn_fwd(qkv: Tensor, B: int, T: int, NH: int, H: int, scale: float, p: float, rng_state: Optional[Tensor], site: int):
     _chk(qkv, "qkv")
     if qkv.shape != (B * T, 3 * NH * H):

@@ -143,6 +143,11 @@ int dg_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, v
 int dg_transpose_cast(const float* in, int64_t ldi, void* out, int64_t ldo, int dtype,
                       int R, int Cc, void* stream);
 
+/* The same for n_desc matrices in ONE launch.  desc: device array of n_desc x 8 int64
+ * {in ptr, out ptr, ldi, ldo, R, Cc, first_tile, tiles_x} where a matrix owns tiles_x * ceil(ldo/64)
+ * consecutive 64x64 tiles starting at first_tile (tiles_x = ceil(Cc/64)); total_tiles = their sum. */
+int dg_transpose_cast_batched(const int64_t* desc, int n_desc, int total_tiles, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Causal multi-head attention -- ref: Head2.forward src/model_component.py:392-405 for every
  * head of MultiHeadAttention3 (:453), i.e. K5's output to K11:

@@ -73,7 +73,10 @@ def test_graph_equals_eager_with_dropout(dev, golden_dir, precision):
             eng.set_batch(fix["x"][it].to(dev), fix["y"][it].to(dev))
             ls.append(eng.step().item())
         out.append(ls)
-    assert out[0] == out[1], out
+    # equal up to the one non-deterministic reduction of the step: the fp32 atomics of the
+    # token-embedding scatter-add (arrival order varies run to run)
+    for a, b in zip(*out):
+        assert abs(a - b) <= 2e-6 * abs(b), out
     assert len(set(out[0])) == 5
 
 

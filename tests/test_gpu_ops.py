@@ -282,3 +282,22 @@ def test_batch_gather_and_softmax(dev):
     logits = torch.randn(3, 5, 80, generator=g).to(dev)
     pr = ops.softmax_rows(logits[:, -1, :])
     assert rel(pr, logits[:, -1, :].double().softmax(-1)) < 1e-6
+
+
+def test_transpose_cast_batched(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    shapes = [(80, 384), (1152, 384), (384, 1536), (50, 36)]
+    for dt in (torch.bfloat16, torch.float32):
+        gr = 8 if dt == torch.bfloat16 else 4
+        pairs = []
+        for R, C in shapes:
+            W = torch.randn(R, C, generator=g).to(dev)
+            Wt = torch.full((C, (R + gr - 1) // gr * gr), float("nan"), dtype=dt, device=dev)
+            pairs.append((W, Wt))
+        table = ops.make_transpose_table(pairs, dev)
+        ops.transpose_cast_batched(*table, dt)
+        for W, Wt in pairs:
+            R = W.shape[0]
+            assert torch.equal(Wt[:, :R].cpu(), W.T.to(dt).cpu())
+            assert torch.all(Wt[:, R:] == 0)
