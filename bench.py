@@ -167,6 +167,8 @@ def kernel_roofline(eng, offsets, peak_tflops):
     records = []          # (symbol, flops, start_event, end_event)
     real_nt, real_tn = ops.gemm_nt, ops.gemm_tn
 
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+
     def nt(A, Bm, out_dtype, **kw):
         M = A.shape[0]
         K = kw.get("K") or A.shape[1]
@@ -175,7 +177,11 @@ def kernel_roofline(eng, offsets, peak_tflops):
         s.record()
         r = real_nt(A, Bm, out_dtype, **kw)
         e.record()
-        sym = f"gemm_nt_kernel<{'bf16' if A.dtype == torch.bfloat16 else 'f32'},{'bf16' if out_dtype == torch.bfloat16 else 'f32'}>"
+        to = "bf16" if out_dtype == torch.bfloat16 else "float"
+        if A.dtype == torch.bfloat16 and K % 64 == 0 and K >= 128:        # dispatch rule of dg_gemm_nt
+            sym = f"gemm_nt_pers_kernel<{to}>"
+        else:
+            sym = f"gemm_nt_kernel<{'bf16' if A.dtype == torch.bfloat16 else 'float'},{to}>"
         records.append((sym, 2.0 * M * N * K, s, e))
         return r
 
@@ -184,7 +190,11 @@ def kernel_roofline(eng, offsets, peak_tflops):
         s.record()
         real_tn(A, Bm, out_part, split_stride, n_splits, P, Q, ldo)
         e.record()
-        sym = "gemm_tn_bf16_kernel" if A.dtype == torch.bfloat16 else "gemm_tn_f32_kernel"
+        tiles = ((P + 127) // 128) * ((Q + 127) // 128)
+        if A.dtype == torch.bfloat16:                                          # dispatch rule of dg_gemm_tn
+            sym = "gemm_tn_glds_kernel" if (A.shape[0] % 64 == 0 and tiles * n_splits <= ncu) else "gemm_tn_bf16_kernel"
+        else:
+            sym = "gemm_tn_f32_kernel"
         records.append((sym, 2.0 * A.shape[0] * P * Q, s, e))
 
     eng.set_offsets(offsets)
@@ -205,8 +215,14 @@ def kernel_roofline(eng, offsets, peak_tflops):
         a[2] += 1
     sym, (fl, sec, n) = max(agg.items(), key=lambda kv: kv[1][1])
     achieved = fl / sec / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC pass (tools/collect_traffic.py), per launch
+    if os.path.exists(tpath):
+        t = json.load(open(tpath)).get("kernels", {}).get(sym)
+        if t:
+            traffic = t["hbm_bytes_per_launch"]
     return {"bound": "mfma", "kernel": sym, "achieved": achieved, "peak": peak_tflops, "unit": "TFLOP/s",
-            "frac": achieved / peak_tflops, "traffic": None, "launches_per_step": n // reps,
+            "frac": achieved / peak_tflops, "traffic": traffic, "launches_per_step": n // reps,
             "avg_launch_us": 1e6 * sec / n, "flops_per_launch": fl / n,
             "all_gemm_symbols": {k: {"tflops": v[0] / v[1] / 1e12, "avg_us": 1e6 * v[1] / v[2], "launches_per_step": v[2] // reps}
                                  for k, v in agg.items()}}

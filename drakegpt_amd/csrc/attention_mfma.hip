@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnP p) {
     float m = -INFINITY, lsum = 0.f;
     const float sc = p.scale * LOG2E;
     const uint32_t key = p.drop ? dg_site_key_dev(p.rng, p.site) : 0u;
-    const uint32_t ebase = (uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T);
+    // Weyl value of element (qi, key 4*hh) -- the per-register key offsets are compile-time constants
+    const uint32_t wbase = ((uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T) + 4u * hh) * DG_WEYL;
 
     u32x4 rk[4], rv[4];
     tile_load(rk, Kb, ld, 0, T, lane);
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnP p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgK, ks, lane), qf[ks], S, 0, 0, 0);
         const int k0 = kt * TILE;
+        const uint32_t wtile = wbase + (uint32_t)k0 * DG_WEYL;
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -187,14 +189,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnP p) {
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mn = fmaxf(m, mx);
-        const float alpha = exp2f(m - mn);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
         m = mn;
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float e = exp2f(S[r] - mn);
+            float e = __builtin_amdgcn_exp2f(S[r] - mn);
             ps += e;
-            if (p.drop) e = dg_keep(key, ebase + (uint32_t)(k0 + krow(r, hh)), p.thr) ? e * p.inv_keep : 0.f;
+            if (p.drop) e = dg_keep_w(key, wtile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DG_WEYL, p.thr) ? e * p.inv_keep : 0.f;
             S[r] = e;
         }
         lsum = lsum * alpha + ps;
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnP p) {
     for (int i = 0; i < 16; ++i) { dQ[0][i] = 0.f; dQ[1][i] = 0.f; }
     const float sc = p.scale * LOG2E;
     const uint32_t key = p.drop ? dg_site_key_dev(p.rng, p.site) : 0u;
-    const uint32_t ebase = (uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T);
+    const uint32_t wbase = ((uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T) + 4u * hh) * DG_WEYL;
 
     u32x4 rk[4], rv[4];
     tile_load(rk, Kb, ld, 0, T, lane);
@@ -293,13 +295,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnP p) {
             dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgV, ks, lane), gf[ks], dP, 0, 0, 0);
         }
         const int k0 = kt * TILE;
+        const uint32_t wtile = wbase + (uint32_t)k0 * DG_WEYL;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kj = k0 + krow(r, hh);
-            float pr = exp2f(S[r] * sc - L2);
+            float pr = __builtin_amdgcn_exp2f(S[r] * sc - L2);
             if (kt == qb && kj > qi) pr = 0.f;
             float dp = dP[r];
-            if (p.drop) dp = dg_keep(key, ebase + (uint32_t)kj, p.thr) ? dp * p.inv_keep : 0.f;
+            if (p.drop) dp = dg_keep_w(key, wtile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DG_WEYL, p.thr) ? dp * p.inv_keep : 0.f;
             S[r] = pr * (dp - dl);
         }
 #pragma unroll
@@ -371,6 +374,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
             dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgG, ks, lane), vf[ks], dP, 0, 0, 0);
         }
         const int q0 = qt * TILE;
+        const uint32_t wrow = (uint32_t)T * DG_WEYL;                          // one query row further
+        const uint32_t wq = (uint32_t)(((uint64_t)bh * T + q0 + 4 * hh) * (uint64_t)T + kj) * DG_WEYL;
         f32x16 Pd;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -383,10 +388,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
                 const bool ok = qi < T;
                 const float L2 = ok ? lse[qi] * LOG2E : 0.f;
                 const float dl = ok ? dlt[qi] : 0.f;
-                float pr = exp2f(S[r] * sc - L2);
+                float pr = __builtin_amdgcn_exp2f(S[r] * sc - L2);
                 if ((qt == kb && kj > qi) || !ok) pr = 0.f;
                 float keepf = 1.f;
-                if (p.drop) keepf = dg_keep(key, (uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T + kj), p.thr) ? p.inv_keep : 0.f;
+                if (p.drop) keepf = dg_keep_w(key, wq + (uint32_t)(8 * g + j) * wrow, p.thr) ? p.inv_keep : 0.f;
                 Pd[r] = pr * keepf;
                 S[r] = pr * (dP[r] * keepf - dl);
             }

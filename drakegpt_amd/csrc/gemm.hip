@@ -20,6 +20,10 @@
 #define BM 128
 #define BN 128
 #define EPI_PITCH 68                         // floats per staged row: 64 + 4 (rows r, r+4 land 16 banks apart)
+#define GL_NST 4                              // LDS-DMA pipeline: stages ...
+#define GL_STAGE 32768                        // ... of 32 KB (two 16 KB operand tiles)
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 #define NT_LDS_BYTES (4 * 64 * EPI_PITCH * 4)  // 69632: four 64x68 fp32 staging slices >= the 4 x 16 KB operand buffers
 
 // ---------------------------------------------------------------------------------------------
@@ -102,9 +106,9 @@ __device__ __forceinline__ void nt_epilogue(const float* stage, int row_base, in
             }
         }
         if (p.drop) {
-            const uint32_t eb = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+            const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = dg_keep(key, eb + e, p.thr) ? v[e] * p.inv_keep : 0.f;
+            for (int e = 0; e < 4; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
         }
         if (p.residual) {
             const float* rp = p.residual + (int64_t)row * p.ldr + col;
@@ -222,10 +226,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
 // permuted per-lane SOURCE chunk -- guide rule 21), three stages stay in flight across the single
 // raw s_barrier of a K step, and waits are counted (never vmcnt(0) inside the loop).
 // 512 threads = 8 waves (4 x 2) of 32 x 64, two waves per SIMD; 128 KB LDS, one workgroup per CU.
-#define GL_NST 4
-#define GL_STAGE 32768
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <typename TO>
 __global__ __launch_bounds__(512) void gemm_nt_glds_kernel(NtParams p) {
@@ -442,9 +442,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(NtParams p) {
                     }
                 }
                 if (p.drop) {
-                    const uint32_t eb = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+                    const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = dg_keep(key, eb + e, p.thr) ? v[e] * p.inv_keep : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
                 }
                 if (p.residual) {
                     const float* rp = p.residual + (int64_t)row * p.ldr + col;
@@ -597,7 +597,25 @@ struct TnParams {
     int R, P, Q;
     int tiles_q, n_tiles;
     int r_per_split;
+    int n_splits, xcd_map;     // xcd_map: 1-D grid, every split's tiles on one XCD (they share the same rows)
 };
+
+// (tile, split) of a workgroup.  Workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the
+// XCD group), and all tiles of one split read the same R rows of both operands: keeping a split on one
+// XCD makes those rows L2 hits for every tile after the first.  Speed only, never correctness.
+__device__ __forceinline__ void tn_work(const TnParams& p, int& tile, int& split) {
+    if (!p.xcd_map) { tile = dg_xcd_remap(blockIdx.x, p.n_tiles); split = blockIdx.y; return; }
+    const int id = blockIdx.x, x = id & 7, rest = id >> 3;
+    if (p.n_splits >= 8) {
+        const int g = p.n_splits >> 3;
+        split = x + 8 * (rest % g);
+        tile = rest / g;
+    } else {
+        const int share = 8 / p.n_splits;                    // XCDs per split
+        split = x % p.n_splits;
+        tile = rest * share + x / p.n_splits;
+    }
+}
 
 // ---- bf16: [64 r][128 cols] tiles, 256-byte rows, dual-use image (b) of the guide (T10):
 //      off(row, ch) = 256*row + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3))),  ch = 16-byte chunk 0..15
@@ -623,9 +641,10 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnParams p) {
     __shared__ __attribute__((aligned(16))) char lds[2][2][BR * 256];      // 64 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave >> 1, wq = wave & 1;
-    const int tile = dg_xcd_remap(blockIdx.x, p.n_tiles);
+    int tile, split;
+    tn_work(p, tile, split);
+    if (tile >= p.n_tiles) return;                          // padding of the 1-D grid (whole workgroup)
     const int p0 = (tile / p.tiles_q) * 128, q0 = (tile % p.tiles_q) * 128;
-    const int split = blockIdx.y;
     const int r_begin = split * p.r_per_split;
     int r_end = r_begin + p.r_per_split; if (r_end > p.R) r_end = p.R;
     const int nk = r_end > r_begin ? (r_end - r_begin + BR - 1) / BR : 0;
@@ -696,6 +715,108 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnParams p) {
     }
 }
 
+// ---- bf16, LDS-DMA form: 8 waves (4 x 2 of 32 x 64), 4 stages of [64 r][128 cols] x 2 operands,
+//      global_load_lds writes image (b) directly (per-lane SOURCE chunk = slot ^ f(row)), counted
+//      vmcnt + one raw barrier per K step, fragments of the next half step always in flight.
+//      Requires whole 64-row steps (R % 64 == 0); column tails read clamped (finite) data that only
+//      reaches outputs which are not stored.  Accumulators transposed (mfma(B, A)): 16-byte stores.
+__global__ __launch_bounds__(512) void gemm_tn_glds_kernel(TnParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wq = wave & 1;
+    int tile, split;
+    tn_work(p, tile, split);
+    if (tile >= p.n_tiles) return;                          // padding of the 1-D grid (whole workgroup)
+    const int p0 = (tile / p.tiles_q) * 128, q0 = (tile % p.tiles_q) * 128;
+    const int r_begin = split * p.r_per_split;
+    int r_end = r_begin + p.r_per_split; if (r_end > p.R) r_end = p.R;
+    const int nk = r_end > r_begin ? (r_end - r_begin) / 64 : 0;
+
+    // piece = 1 KB = 4 rows x 256 B; this wave moves pieces 2w, 2w+1 of A and of B per stage
+    const int prow = lane >> 4, slot = lane & 15;
+    const char* srcA[2];
+    const char* srcB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = 2 * wave + i;
+        const int row = 4 * q + prow;
+        const int chunk = slot ^ ((prow << 2) | (q & 3));           // f(row) of image (b): ((row&3)<<2)|((row>>2)&3)
+        int ca = p0 + chunk * 8; if (ca + 8 > p.lda_b / 2) ca = 0;   // past the leading dimension: clamp
+        int cb = q0 + chunk * 8; if (cb + 8 > p.ldb_b / 2) cb = 0;
+        srcA[i] = p.A + (int64_t)(r_begin + row) * p.lda_b + (int64_t)ca * 2;
+        srcB[i] = p.B + (int64_t)(r_begin + row) * p.ldb_b + (int64_t)cb * 2;
+    }
+    auto issue = [&](int kt) {
+        char* base = lds + (kt & (GL_NST - 1)) * GL_STAGE + (2 * wave) * 1024;
+        const int64_t ra = (int64_t)kt * 64 * p.lda_b, rb = (int64_t)kt * 64 * p.ldb_b;
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[0] + ra), (lptr_t)(base), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[1] + ra), (lptr_t)(base + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcB[0] + rb), (lptr_t)(base + 16384), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcB[1] + rb), (lptr_t)(base + 16384 + 1024), 16, 0, 0);
+    };
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    auto read_frags = [&](u32x4 (&fa)[2], u32x4 (&fb)[4], const char* buf, int ks) {
+        const int r0 = ks * 32 + fg * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = tn_frag_bf16(buf, r0, wp * 32 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = tn_frag_bf16(buf + 16384, r0, wq * 64 + j * 16, lane);
+    };
+    auto mma_all = [&](const u32x4 (&fa)[2], const u32x4 (&fb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
+    };
+    if (nk > 0) {
+        const int npre = nk < GL_NST - 1 ? nk : GL_NST - 1;
+        for (int g = 0; g < npre; ++g) issue(g);
+        u32x4 fa0[2], fb0[4], fa1[2], fb1[4];
+        if (npre >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (npre == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(fa0, fb0, lds, 0);
+        for (int g = 0; g < nk; ++g) {
+            const char* buf = lds + (g & (GL_NST - 1)) * GL_STAGE;
+            read_frags(fa1, fb1, buf, 1);
+            mma_all(fa0, fb0);
+            if (g + 1 < nk) {
+                int issued = g + GL_NST - 1; if (issued > nk) issued = nk;
+                if (issued - (g + 2) >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (g + GL_NST - 1 < nk) issue(g + GL_NST - 1);
+                read_frags(fa0, fb0, lds + ((g + 1) & (GL_NST - 1)) * GL_STAGE, 0);
+            }
+            mma_all(fa1, fb1);
+        }
+    }
+    float* out = p.out + (int64_t)split * p.split_stride;
+    const bool vec = (p.ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = p0 + wp * 32 + i * 16 + fr;
+        if (row >= p.P) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = q0 + wq * 64 + j * 16 + 4 * fg;
+            float* op = out + (int64_t)row * p.ldo + col;
+            if (vec && col + 3 < p.Q) *(f32x4*)op = acc[i][j];
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < p.Q) op[e] = acc[i][j][e];
+            }
+        }
+    }
+}
+
 // ---- f32: [32 r][128 cols] tiles with 144-float row pitch (pad 16 floats: rows r, r+1 of one
 //      ds_read_b32 half-wave land on different banks)
 #define TNF_PITCH 144
@@ -704,9 +825,10 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(TnParams p) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][BR * TNF_PITCH];     // 73.7 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave >> 1, wq = wave & 1;
-    const int tile = dg_xcd_remap(blockIdx.x, p.n_tiles);
+    int tile, split;
+    tn_work(p, tile, split);
+    if (tile >= p.n_tiles) return;                          // padding of the 1-D grid (whole workgroup)
     const int p0 = (tile / p.tiles_q) * 128, q0 = (tile % p.tiles_q) * 128;
-    const int split = blockIdx.y;
     const int r_begin = split * p.r_per_split;
     int r_end = r_begin + p.r_per_split; if (r_end > p.R) r_end = p.R;
     const int nk = r_end > r_begin ? (r_end - r_begin + BR - 1) / BR : 0;
@@ -797,9 +919,21 @@ extern "C" int dg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
     const int br = dtype == DG_BF16 ? 64 : 32;
     int per = (R + n_splits - 1) / n_splits;
     p.r_per_split = ((per + br - 1) / br) * br;
+    p.n_splits = n_splits;
+    p.xcd_map = (n_splits % 8 == 0 || n_splits == 1 || n_splits == 2 || n_splits == 4) ? 1 : 0;
     dim3 grid(p.n_tiles, n_splits), block(256);
+    if (p.xcd_map) {
+        const int per_x = n_splits >= 8 ? p.n_tiles * (n_splits / 8) : (p.n_tiles + (8 / n_splits) - 1) / (8 / n_splits);
+        grid = dim3(per_x * 8, 1);
+    }
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == DG_BF16) hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, block, 0, s, p);
+    static const int tn_mode = [] { const char* e = getenv("DG_GEMM_TN"); return e ? atoi(e) : 0; }();   // 1 = register-staged
+    // the LDS-DMA kernel owns a CU (128 KB LDS): use it when the launch fits one wave of workgroups,
+    // otherwise two register-staged workgroups per CU finish sooner than a second round
+    const bool one_round = (int64_t)p.n_tiles * n_splits <= dg_num_cus();
+    if (dtype == DG_BF16 && R % 64 == 0 && (tn_mode == 2 || (tn_mode == 0 && one_round)))
+        hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, dim3(512), 0, s, p);
+    else if (dtype == DG_BF16) hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, block, 0, s, p);
     else hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, block, 0, s, p);
     DG_LAUNCH_CHECK();
     return DG_OK;

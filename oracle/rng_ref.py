@@ -37,11 +37,18 @@ def threshold(p: float) -> int:
     return min(int(p * 4294967296.0), 0xFFFFFFFF)
 
 
+def element_hash(key: int, idx: np.ndarray) -> np.ndarray:
+    """dg_keep_w in common.h: Weyl step, one xorshift32 round, one multiply."""
+    x = np.uint64(key) ^ ((idx.astype(np.uint64) * np.uint64(0x9E3779B1)) & _M32)
+    x ^= x >> np.uint64(17)
+    x ^= (x << np.uint64(11)) & _M32
+    x ^= x >> np.uint64(13)
+    return (x * np.uint64(0x7FEB352D)) & _M32
+
+
 def keep_mask(seed: int, step: int, site: int, p: float, n: int) -> np.ndarray:
     """keep[i] for linear element indices i in [0, n) (n < 2^32) as float32 {0,1}."""
-    key = np.uint64(site_key(seed, step, site))
-    idx = np.arange(n, dtype=np.uint64)
-    r = _mix32(key ^ ((idx * np.uint64(0x9E3779B1)) & _M32))
+    r = element_hash(site_key(seed, step, site), np.arange(n, dtype=np.uint64))
     return (r >= np.uint64(threshold(p))).astype(np.float32)
 
 

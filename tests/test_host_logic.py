@@ -119,3 +119,11 @@ def test_dropout_hash_reference_properties():
     assert not (m == rng_ref.keep_mask(1, 0, 1, 0.2, 200000)).all()      # site re-keys the stream
     assert (m == rng_ref.keep_mask(1, 0, 0, 0.2, 200000)).all()
     assert rng_ref.threshold(0.0) == 0 and rng_ref.threshold(0.5) == 2 ** 31
+    # the lean element hash behaves like independent Bernoulli draws: lag correlations ~ 1/sqrt(n),
+    # row sums (256 consecutive elements = one attention row) binomially dispersed
+    import numpy as np
+    k = rng_ref.keep_mask(7, 3, 5, 0.2, 256 * 8192).astype(np.float64)
+    for lag in (1, 2, 3, 8, 256, 257, 384):
+        assert abs(np.corrcoef(k[:-lag], k[lag:])[0, 1]) < 4e-3, lag
+    rows = k.reshape(-1, 256).sum(1)
+    assert 0.93 < rows.var() / (256 * 0.2 * 0.8) < 1.07
