@@ -48,6 +48,7 @@ SIGNATURES = {
     "dg_embed_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "dg_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp],
     "dg_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "dg_layernorm_bwd_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _vp, _u32, _vp, _vp],
     "dg_gemm_nt": [C.POINTER(GemmNtArgs), _vp],
     "dg_gemm_tn": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp],
     "dg_reduce_partials": [_vp, _i64, _i, _vp, _i64, _vp],

@@ -351,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
     const uint32_t key = p.drop ? dg_site_key_dev(p.rng, p.site) : 0u;
     const float* lse = p.lse_r + bh * T;
     const float* dlt = p.delta_r + bh * T;
+    const bool vec4 = (T % 4 == 0) && ((((uintptr_t)p.lse_r) & 15) == 0) && ((((uintptr_t)p.delta_r) & 15) == 0);
 
     u32x4 rq[4], rg[4];
     tile_load(rq, Qb, ld, k0, T, lane);
@@ -381,13 +382,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
         for (int g = 0; g < 4; ++g) {
             // rows q0 + 8g + 4hh + 0..3
             const int qr = q0 + 8 * g + 4 * hh;
+            // row constants of 4 consecutive queries: one 16-byte load each instead of 8 scalar loads
+            f32x4 L4 = {0.f, 0.f, 0.f, 0.f}, D4 = {0.f, 0.f, 0.f, 0.f};
+            if (vec4 && qr + 3 < T) { L4 = *(const f32x4*)(lse + qr); D4 = *(const f32x4*)(dlt + qr); }
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (qr + j < T) { L4[j] = lse[qr + j]; D4[j] = dlt[qr + j]; }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * g + j;
                 const int qi = qr + j;
                 const bool ok = qi < T;
-                const float L2 = ok ? lse[qi] * LOG2E : 0.f;
-                const float dl = ok ? dlt[qi] : 0.f;
+                const float L2 = L4[j] * LOG2E;
+                const float dl = D4[j];
                 float pr = __builtin_amdgcn_exp2f(S[r] * sc - L2);
                 if ((qt == kb && kj > qi) || !ok) pr = 0.f;
                 float keepf = 1.f;

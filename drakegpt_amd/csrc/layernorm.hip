@@ -113,8 +113,14 @@ extern "C" int dg_layernorm_fwd(const float* x, const float* gamma, const float*
 //   dx = rstd * (g - mean(g) - xhat*mean(g*xhat)) (+ dresid).
 // dgamma/dbeta column partials accumulate in registers per lane, are combined across the 4 waves
 // through LDS and written as partial #blockIdx.x.
-template <bool VEC, int LN_MAXV, int NTHREADS>
-__global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// FUSE_G: additionally emit g = (TG)(dx * keep/(1-p)) -- the operand the NEXT backward sub-layer would
+// otherwise produce with dg_dropout_bwd_cast from this kernel's dx -- and its column-sum partials
+// (that sub-layer's bias gradient).  Saves one 38 MB pass and one launch per sub-layer.
+struct LnFuse {
+    void* g; float* gbias_part; float inv_keep; uint32_t thr; int drop; const uint32_t* rng; uint32_t site;
+};
+template <bool VEC, int LN_MAXV, int NTHREADS, int FUSE_G /*0 none, 1 bf16, 2 f32*/>
+__global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const float* __restrict__ dy, const float* __restrict__ x,
                               const float* __restrict__ gamma, const float* __restrict__ mean,
                               const float* __restrict__ rstd, const float* __restrict__ dresid,
                               float* __restrict__ dx, float* __restrict__ dgamma_part,
@@ -128,14 +134,17 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(const float* __restric
     const float invC = 1.f / (float)C;
     if (VEC) {
         const int nv = C >> 2;
-        f32x4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV];
+        f32x4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV], gb[LN_MAXV];
 #pragma unroll
         for (int k = 0; k < LN_MAXV; ++k) {
             int i = lane + k * 64;
             gam[k] = (i < nv) ? ((const f32x4*)gamma)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
             dg[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
             db[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            gb[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        uint32_t fkey = 0;
+        if (FUSE_G && fz.drop) fkey = dg_site_key_dev(fz.rng, fz.site);
         for (int row = m_begin + w; row < m_end; row += NW) {
             const float mu = mean[row], rs = rstd[row];
             const f32x4* dyr = (const f32x4*)(dy + (int64_t)row * C);
@@ -170,24 +179,46 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(const float* __restric
                     for (int j = 0; j < 4; ++j) o[j] = rs * (gv[k][j] - c1 - xh[k][j] * c2);
                     if (drr) o += drr[i];
                     dxr[i] = o;
+                    if (FUSE_G) {
+                        f32x4 gq = o;
+                        if (fz.drop) {
+                            const uint32_t wb = ((uint32_t)row * (uint32_t)C + (uint32_t)(i * 4)) * DG_WEYL;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) gq[j] = dg_keep_w(fkey, wb + (uint32_t)j * DG_WEYL, fz.thr) ? o[j] * fz.inv_keep : 0.f;
+                        }
+                        gb[k] += gq;
+                        if (FUSE_G == 1) {
+                            bf16x4 t;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) t[j] = (bf16_t)gq[j];
+                            *(bf16x4*)((bf16_t*)fz.g + (int64_t)row * C + i * 4) = t;
+                        } else {
+                            *(f32x4*)((float*)fz.g + (int64_t)row * C + i * 4) = gq;
+                        }
+                    }
                 }
             }
         }
         // combine the waves' column partials
         float* lg = lds;               // [NW][C]
         float* lb = lds + NW * C;      // [NW][C]
+        float* lq = lds + 2 * NW * C;  // [NW][C]  (FUSE_G)
 #pragma unroll
         for (int k = 0; k < LN_MAXV; ++k) {
             int i = lane + k * 64;
-            if (i < nv) { *(f32x4*)(lg + w * C + i * 4) = dg[k]; *(f32x4*)(lb + w * C + i * 4) = db[k]; }
+            if (i < nv) {
+                *(f32x4*)(lg + w * C + i * 4) = dg[k]; *(f32x4*)(lb + w * C + i * 4) = db[k];
+                if (FUSE_G) *(f32x4*)(lq + w * C + i * 4) = gb[k];
+            }
         }
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            float a = 0.f, b = 0.f;
+            float a = 0.f, b = 0.f, q = 0.f;
 #pragma unroll
-            for (int k = 0; k < NW; ++k) { a += lg[k * C + c]; b += lb[k * C + c]; }
+            for (int k = 0; k < NW; ++k) { a += lg[k * C + c]; b += lb[k * C + c]; if (FUSE_G) q += lq[k * C + c]; }
             dgamma_part[(int64_t)blockIdx.x * part_stride + c] = a;
             dbeta_part[(int64_t)blockIdx.x * part_stride + c] = b;
+            if (FUSE_G) fz.gbias_part[(int64_t)blockIdx.x * part_stride + c] = q;
         }
     } else {
         // generic path: any C; column partials accumulate directly in LDS [2][NW][C] per wave
@@ -223,30 +254,66 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(const float* __restric
     }
 }
 
-extern "C" int dg_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                                const float* rstd, const float* dresid, float* dx,
-                                float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
-                                int M, int C, void* stream) {
+static int ln_bwd_launch(LnFuse fz, int fuse, const float* dy, const float* x, const float* gamma, const float* mean,
+                         const float* rstd, const float* dresid, float* dx,
+                         float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
+                         int M, int C, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma_part || !dbeta_part) return DG_ERR_ARG;
     if (M <= 0 || C <= 0 || n_partials <= 0 || part_stride < C) return DG_ERR_ARG;
-    // more waves per workgroup = more rows in flight per partial (HBM-bound: needs the occupancy)
-    const int nthreads = C <= 512 ? 1024 : (C <= 1024 ? 512 : 256);
-    size_t lds_bytes = (size_t)2 * (nthreads / 64) * C * sizeof(float);
     bool vec = (C % 4 == 0) && (C <= 64 * 4 * LN_MAXV_CAP) && dg_aligned16(dy) && dg_aligned16(x) && dg_aligned16(gamma) &&
                dg_aligned16(dx) && (!dresid || dg_aligned16(dresid));
+    const int nk = (C / 4 + 63) / 64;
+    if (fuse && (!vec || nk > 4 || !fz.g || !fz.gbias_part || !dg_aligned16(fz.g))) return DG_ERR_ARG;
+    // more waves per workgroup = more rows in flight per partial (HBM-bound: needs the occupancy)
+    int nthreads = C <= 512 ? 1024 : (C <= 1024 ? 512 : 256);
+    if (fuse && nthreads == 1024) nthreads = 512;           // a third [NW][C] LDS array: stay under 64 KB
+    size_t lds_bytes = (size_t)(fuse ? 3 : 2) * (nthreads / 64) * C * sizeof(float);
     int rows_per = (M + n_partials - 1) / n_partials;
     dim3 grid(n_partials), block(nthreads);
     hipStream_t s = (hipStream_t)stream;
     if (lds_bytes > 64 * 1024) return DG_ERR_ARG;   // C <= 2048 on either path
-    const int nk = (C / 4 + 63) / 64;
-#define LAUNCH(V, K, NT) hipLaunchKernelGGL((ln_bwd_kernel<V, K, NT>), grid, block, lds_bytes, s, dy, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part, part_stride, M, C, rows_per)
-    if (!vec) { if (nthreads == 1024) LAUNCH(false, 1, 1024); else if (nthreads == 512) LAUNCH(false, 1, 512); else LAUNCH(false, 1, 256); }
-    else if (nk <= 1) LAUNCH(true, 1, 1024);
-    else if (nk == 2) LAUNCH(true, 2, 1024);
-    else if (nk == 3) LAUNCH(true, 3, 512);
-    else if (nk == 4) LAUNCH(true, 4, 512);
-    else LAUNCH(true, 8, 256);
+#define LAUNCH(V, K, NT, F) hipLaunchKernelGGL((ln_bwd_kernel<V, K, NT, F>), grid, block, lds_bytes, s, fz, dy, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part, part_stride, M, C, rows_per)
+    if (fuse == 0) {
+        if (!vec) { if (nthreads == 1024) LAUNCH(false, 1, 1024, 0); else if (nthreads == 512) LAUNCH(false, 1, 512, 0); else LAUNCH(false, 1, 256, 0); }
+        else if (nk <= 1) LAUNCH(true, 1, 1024, 0);
+        else if (nk == 2) LAUNCH(true, 2, 1024, 0);
+        else if (nk == 3) LAUNCH(true, 3, 512, 0);
+        else if (nk == 4) LAUNCH(true, 4, 512, 0);
+        else LAUNCH(true, 8, 256, 0);
+    } else if (fuse == 1) {
+        if (nk <= 1) LAUNCH(true, 1, 512, 1); else if (nk == 2) LAUNCH(true, 2, 512, 1);
+        else if (nk == 3) LAUNCH(true, 3, 512, 1); else LAUNCH(true, 4, 512, 1);
+    } else {
+        if (nk <= 1) LAUNCH(true, 1, 512, 2); else if (nk == 2) LAUNCH(true, 2, 512, 2);
+        else if (nk == 3) LAUNCH(true, 3, 512, 2); else LAUNCH(true, 4, 512, 2);
+    }
 #undef LAUNCH
     DG_LAUNCH_CHECK();
     return DG_OK;
+}
+
+extern "C" int dg_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                const float* rstd, const float* dresid, float* dx,
+                                float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
+                                int M, int C, void* stream) {
+    LnFuse fz = {};
+    return ln_bwd_launch(fz, 0, dy, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part, part_stride, n_partials, M, C, stream);
+}
+
+extern "C" int dg_layernorm_bwd_fused(const float* dy, const float* x, const float* gamma, const float* mean,
+                                      const float* rstd, const float* dresid, float* dx,
+                                      float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
+                                      int M, int C,
+                                      void* g, int g_dtype, float dropout_p, const uint32_t* rng_state, uint32_t site,
+                                      float* gbias_part, void* stream) {
+    if (g_dtype != DG_BF16 && g_dtype != DG_F32) return DG_ERR_DTYPE;
+    if (dropout_p < 0.f || dropout_p >= 1.f) return DG_ERR_ARG;
+    LnFuse fz;
+    fz.g = g; fz.gbias_part = gbias_part;
+    fz.drop = (dropout_p > 0.f && rng_state) ? 1 : 0;
+    fz.inv_keep = 1.f / (1.f - dropout_p);
+    fz.thr = dg_drop_threshold(dropout_p);
+    fz.rng = rng_state; fz.site = site;
+    return ln_bwd_launch(fz, g_dtype == DG_BF16 ? 1 : 2, dy, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part,
+                         part_stride, n_partials, M, C, stream);
 }

@@ -276,13 +276,22 @@ class TrainEngine:
         p = self.p_drop
         sink = FlatSink(self)
         dh = S.linear_bwd_from_act(run, (xa,), dlogits[:, :self.V], self.param_view("lm.w"), True, sink, {"w": "lm.w", "b": "lm.b"})
+        g_next = None            # dropout-backward of dh for the sub-layer that runs next, fused into the LN backward
         for l in reversed(range(self.L)):
             P = self._layer_params(l)
             sa, sf = saved[l]
-            dh = S.ffn_bwd(run, sf, dh, P["ln2w"], P["w1"], P["w2"], True, p, l, sink,
-                           {"w1": f"{l}.w1", "b1": f"{l}.b1", "w2": f"{l}.w2", "b2": f"{l}.b2", "ln_w": f"{l}.ln2w", "ln_b": f"{l}.ln2b"})
-            dh = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink,
-                            {"wqkv": f"{l}.wqkv", "wproj": f"{l}.wproj", "bproj": f"{l}.bproj", "ln_w": f"{l}.ln1w", "ln_b": f"{l}.ln1b"})
+            dh, g_next = S.ffn_bwd(run, sf, dh, P["ln2w"], P["w1"], P["w2"], True, p, l, sink,
+                                   {"w1": f"{l}.w1", "b1": f"{l}.b1", "w2": f"{l}.w2", "b2": f"{l}.b2", "ln_w": f"{l}.ln2w", "ln_b": f"{l}.ln2b"},
+                                   g_in=g_next, emit=(p, S.site_proj(l), f"{l}.bproj", self.C))
+            emit = (p, S.site_ffn(l - 1), f"{l - 1}.b2", self.C) if l > 0 else (0.0, 0, None, 0)
+            if l > 0:
+                dh, g_next = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink,
+                                        {"wqkv": f"{l}.wqkv", "wproj": f"{l}.wproj", "bproj": f"{l}.bproj", "ln_w": f"{l}.ln1w", "ln_b": f"{l}.ln1b"},
+                                        g_in=g_next, emit=emit)
+            else:
+                dh = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink,
+                                {"wqkv": f"{l}.wqkv", "wproj": f"{l}.wproj", "bproj": f"{l}.bproj", "ln_w": f"{l}.ln1w", "ln_b": f"{l}.ln1b"},
+                                g_in=g_next)
         ops.embed_bwd(x_idx, dh.view(B, T, self.C), self.grad_view("tok"), self.grad_view("pos")[:T])
         ops.reduce_partials(self.slabs, self.layA.size, self.S, self.gflat[self.offA:], self.layA.size)
         ops.reduce_partials(self.vparts, self.layB.size, self.G, self.gflat[self.offB:], self.layB.size)

@@ -135,6 +135,26 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     return dx
 
 
+def layernorm_bwd_fused(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dresid: Optional[Tensor],
+                        dgamma_part: Tensor, dbeta_part: Tensor, part_stride: int, n_partials: int,
+                        g_dtype: torch.dtype, p: float, rng_state: Optional[Tensor], site: int, gbias_part: Tensor):
+    """layernorm_bwd that also emits g = dropout_bwd(dx) in g_dtype and its column-sum partials; returns (dx, g)."""
+    _chk(dy, "dy", torch.float32)
+    _chk(x, "x", torch.float32)
+    Cd = x.shape[-1]
+    M = x.numel() // Cd
+    dx = torch.empty_like(x)
+    g = torch.empty(x.shape, dtype=g_dtype, device=x.device)
+    check(lib.dg_layernorm_bwd_fused(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dresid), _p(dx), _p(dgamma_part),
+                                     _p(dbeta_part), part_stride, n_partials, M, Cd, _p(g), dt_code(g_dtype), float(p),
+                                     _p(rng_state) if p > 0.0 else None, site, _p(gbias_part), _stream()), "dg_layernorm_bwd_fused")
+    return dx, g
+
+
+def layernorm_bwd_fused_supported(C: int) -> bool:
+    return C % 4 == 0 and C <= 1024
+
+
 def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] = None, K: Optional[int] = None,
             bias: Optional[Tensor] = None, relu: bool = False, relu_mask: Optional[Tensor] = None,
             residual: Optional[Tensor] = None, dropout_p: float = 0.0, rng_state: Optional[Tensor] = None,

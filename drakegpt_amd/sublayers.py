@@ -123,6 +123,18 @@ def _as_act(run: Run, x2d: Tensor) -> Tensor:
     return x2d if x2d.dtype == run.act else ops.cast(x2d, run.act)
 
 
+def _ln_tail(run: Run, dh: Tensor, x2d: Tensor, ln_w: Tensor, mean, rstd, dresid, sink, keys, emit):
+    """LayerNorm backward (+ residual-branch gradient).  With `emit = (p, site, bias_key, N)` the kernel also
+    produces g = dropout_bwd(dx) for the sub-layer that runs next in backward, and that sub-layer's bias partials."""
+    pg, sg, ng = sink.vector(keys["ln_w"], ln_w.numel())
+    pb, _, _ = sink.vector(keys["ln_b"], ln_w.numel())
+    if emit is not None and ops.layernorm_bwd_fused_supported(ln_w.numel()):
+        p, site, bias_key, N = emit
+        pq, _, _ = sink.vector(bias_key, N)
+        return ops.layernorm_bwd_fused(dh, x2d, ln_w, mean, rstd, dresid, pg, pb, sg, ng, run.act, run.p(p), run.rng, site, pq)
+    return ops.layernorm_bwd(dh, x2d, ln_w, mean, rstd, dresid, pg, pb, sg, ng), None
+
+
 # ------------------------------------------------------------------------------------------------
 # attention sub-layer
 def attn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor], wqkv: Tensor,
@@ -147,13 +159,18 @@ def attn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tenso
 
 def attn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], wqkv: Tensor, wproj: Optional[Tensor],
              residual: bool, B: int, T: int, NH: int, H: int, p_attn: float, p_proj: float, layer: int,
-             sink, keys: Dict[str, str], need_dx: bool = True) -> Optional[Tensor]:
+             sink, keys: Dict[str, str], need_dx: bool = True, g_in: Optional[Tensor] = None, emit=None):
+    """Returns dx, or (dx, g_next) when `emit` is given (engine path; see _ln_tail).  `g_in`: dropout-backward of dy
+    already produced (with the proj bias partials) by the previous LayerNorm backward."""
     x2d, h, mean, rstd, qkv, o, lse = saved
     M = x2d.shape[0]
     if wproj is not None:
-        part, stride, n = sink.vector(keys["bproj"], wproj.shape[0])
-        g = ops.dropout_bwd_cast(dy, run.act, run.p(p_proj), run.rng, site_proj(layer), colsum_part=part,
-                                 part_stride=stride, n_partials=n)
+        if g_in is not None:
+            g = g_in
+        else:
+            part, stride, n = sink.vector(keys["bproj"], wproj.shape[0])
+            g = ops.dropout_bwd_cast(dy, run.act, run.p(p_proj), run.rng, site_proj(layer), colsum_part=part,
+                                     part_stride=stride, n_partials=n)
         part, stride, n = sink.matrix(keys["wproj"], wproj.shape[0], wproj.shape[1])
         ops.gemm_tn(g, o, part, stride, n, wproj.shape[0], wproj.shape[1])
         do = ops.gemm_nt(g, run.weights.bwd(wproj), run.act, K=wproj.shape[0])
@@ -166,10 +183,10 @@ def attn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], wqkv: Tensor, 
         return None
     if ln_w is not None:
         dh = ops.gemm_nt(dqkv, run.weights.bwd(wqkv), torch.float32, K=wqkv.shape[0])
-        pg, sg, ng = sink.vector(keys["ln_w"], ln_w.numel())
-        pb, _, _ = sink.vector(keys["ln_b"], ln_w.numel())
-        return ops.layernorm_bwd(dh, x2d, ln_w, mean, rstd, dy if residual else None, pg, pb, sg, ng)
-    return ops.gemm_nt(dqkv, run.weights.bwd(wqkv), torch.float32, K=wqkv.shape[0], residual=dy if residual else None)
+        dx, g_next = _ln_tail(run, dh, x2d, ln_w, mean, rstd, dy if residual else None, sink, keys, emit)
+        return (dx, g_next) if emit is not None else dx
+    dx = ops.gemm_nt(dqkv, run.weights.bwd(wqkv), torch.float32, K=wqkv.shape[0], residual=dy if residual else None)
+    return (dx, None) if emit is not None else dx
 
 
 # ------------------------------------------------------------------------------------------------
@@ -191,15 +208,19 @@ def ffn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor
 
 
 def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2: Optional[Tensor], residual: bool,
-            p: float, layer: int, sink, keys: Dict[str, str], need_dx: bool = True) -> Optional[Tensor]:
+            p: float, layer: int, sink, keys: Dict[str, str], need_dx: bool = True, g_in: Optional[Tensor] = None,
+            emit=None):
     x2d, h, mean, rstd, f = saved
     if w2 is None:
         part, stride, n = sink.vector(keys["b1"], w1.shape[0])
         df = ops.dropout_bwd_cast(dy, run.act, 0.0, None, 0, relu_mask=f, colsum_part=part, part_stride=stride, n_partials=n)
     else:
-        part, stride, n = sink.vector(keys["b2"], w2.shape[0])
-        g = ops.dropout_bwd_cast(dy, run.act, run.p(p), run.rng, site_ffn(layer), colsum_part=part, part_stride=stride,
-                                 n_partials=n)
+        if g_in is not None:
+            g = g_in
+        else:
+            part, stride, n = sink.vector(keys["b2"], w2.shape[0])
+            g = ops.dropout_bwd_cast(dy, run.act, run.p(p), run.rng, site_ffn(layer), colsum_part=part, part_stride=stride,
+                                     n_partials=n)
         part, stride, n = sink.matrix(keys["w2"], w2.shape[0], w2.shape[1])
         ops.gemm_tn(g, f, part, stride, n, w2.shape[0], w2.shape[1])
         df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], relu_mask=f)
@@ -211,10 +232,10 @@ def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2:
         return None
     if ln_w is not None:
         dh = ops.gemm_nt(df, run.weights.bwd(w1), torch.float32, K=w1.shape[0])
-        pg, sg, ng = sink.vector(keys["ln_w"], ln_w.numel())
-        pb, _, _ = sink.vector(keys["ln_b"], ln_w.numel())
-        return ops.layernorm_bwd(dh, x2d, ln_w, mean, rstd, dy if residual else None, pg, pb, sg, ng)
-    return ops.gemm_nt(df, run.weights.bwd(w1), torch.float32, K=w1.shape[0], residual=dy if residual else None)
+        dx, g_next = _ln_tail(run, dh, x2d, ln_w, mean, rstd, dy if residual else None, sink, keys, emit)
+        return (dx, g_next) if emit is not None else dx
+    dx = ops.gemm_nt(df, run.weights.bwd(w1), torch.float32, K=w1.shape[0], residual=dy if residual else None)
+    return (dx, None) if emit is not None else dx
 
 
 # ------------------------------------------------------------------------------------------------

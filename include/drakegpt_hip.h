@@ -83,6 +83,18 @@ int dg_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
                      float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
                      int M, int C, void* stream);
 
+/* The same, and additionally g[m,c] = (g_dtype)(dx[m,c] * keep/(1-p)) with its column-sum partials in
+ * gbias_part (same stride / count as dgamma_part): the operand and the bias gradient that the sub-layer
+ * which runs next in backward would otherwise get from dg_dropout_bwd_cast(dx, site) -- one 38 MB pass and
+ * one launch less per sub-layer.  Returns DG_ERR_ARG for shapes the fused kernel does not cover
+ * (C % 4 != 0 or C > 1024): call dg_layernorm_bwd + dg_dropout_bwd_cast then. */
+int dg_layernorm_bwd_fused(const float* dy, const float* x, const float* gamma, const float* mean,
+                           const float* rstd, const float* dresid, float* dx,
+                           float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
+                           int M, int C,
+                           void* g, int g_dtype, float dropout_p, const uint32_t* rng_state, uint32_t site,
+                           float* gbias_part, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * GEMM "NT": C[M,N] = epilogue(A[M,K] . B[N,K]^T), MFMA with fp32 accumulation.
  * Replaces every nn.Linear forward (y = x W^T + b; W is [out,in]) -- ref:
