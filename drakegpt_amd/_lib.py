@@ -59,6 +59,7 @@ SIGNATURES = {
     "dg_transpose_cast_batched": [_vp, _i, _i, _i, _vp],
     "dg_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
     "dg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
+    "dg_attn_decode": [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dg_cross_entropy": [_vp, _i64, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _i, _vp],
     "dg_reduce_sum": [_vp, _i64, _f, _vp, _vp],
     "dg_softmax_rows": [_vp, _i64, _vp, _i64, _i, _i, _vp],

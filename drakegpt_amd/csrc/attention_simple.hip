@@ -169,6 +169,68 @@ __global__ void attn_bwd_dkv_simple_kernel(const T* __restrict__ qkv, const T* _
 }
 
 // ---------------------------------------------------------------------------------------------
+// Single-query decode against a K/V cache kept in the training layout: cache [B, Tcap, 3*NH*H] rows are
+// positions, the new token's q/k/v row t has just been written by the QKV GEMM.  One wave per (b, h); the
+// arithmetic (and its order) is that of attn_fwd_simple_kernel for query row t, so cached decoding
+// reproduces the uncached forward bit for bit in fp32 mode.  ref: generate() re-runs the whole forward
+// per token (src/model.py:625-635); this removes the O(T^2) recompute while the window has not slid.
+template <typename T>
+__global__ void attn_decode_kernel(const T* __restrict__ cache, T* __restrict__ out, int B, int Tcap, int t,
+                                   int NH, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int Tn = t + 1;
+    float* sc = smem + w * (Tcap + H);
+    float* qs = sc + Tcap;
+    const int gid = blockIdx.x * AS_WAVES + w;            // (b, h)
+    if (gid >= B * NH) return;
+    const int h = gid % NH, b = gid / NH;
+    const int64_t ld = 3 * (int64_t)NH * H;
+    const T* base = cache + (int64_t)b * Tcap * ld + h * H;
+    const T* qr = base + (int64_t)t * ld;
+    for (int d = lane; d < H; d += 64) qs[d] = to_f32<T>(qr[d]);
+    __builtin_amdgcn_wave_barrier();
+    float mx = -INFINITY;
+    for (int j = lane; j < Tn; j += 64) {
+        const T* kr = base + (int64_t)j * ld + NH * H;
+        float s = 0.f;
+        for (int d = 0; d < H; ++d) s += qs[d] * to_f32<T>(kr[d]);
+        s *= scale;
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < Tn; j += 64) { float e = expf(sc[j] - mx); sc[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int j = lane; j < Tn; j += 64) sc[j] *= inv;
+    __builtin_amdgcn_wave_barrier();
+    T* orow = out + (int64_t)b * (NH * H) + h * H;
+    for (int d = lane; d < H; d += 64) {
+        float o = 0.f;
+        for (int j = 0; j < Tn; ++j) o += sc[j] * to_f32<T>(base[(int64_t)j * ld + 2 * NH * H + d]);
+        orow[d] = from_f32<T>(o);
+    }
+}
+
+extern "C" int dg_attn_decode(const void* qkv_cache, void* out, int B, int Tcap, int t, int NH, int H,
+                              float scale, int dtype, void* stream) {
+    if (!qkv_cache || !out || B <= 0 || Tcap <= 0 || t < 0 || t >= Tcap || NH <= 0 || H <= 0 || H > 256 || Tcap > 8192)
+        return DG_ERR_ARG;
+    dim3 grid((B * NH + AS_WAVES - 1) / AS_WAVES), block(64 * AS_WAVES);
+    size_t sm = (size_t)AS_WAVES * (Tcap + H) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DG_BF16)
+        hipLaunchKernelGGL(attn_decode_kernel<bf16_t>, grid, block, sm, s, (const bf16_t*)qkv_cache, (bf16_t*)out, B, Tcap, t, NH, H, scale);
+    else if (dtype == DG_F32)
+        hipLaunchKernelGGL(attn_decode_kernel<float>, grid, block, sm, s, (const float*)qkv_cache, (float*)out, B, Tcap, t, NH, H, scale);
+    else return DG_ERR_DTYPE;
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 static int check_common(int B, int T, int NH, int H, float p) {
     if (B <= 0 || T <= 0 || NH <= 0 || H <= 0 || H > 256 || T > 4096) return DG_ERR_ARG;
     if (p < 0.f || p >= 1.f) return DG_ERR_ARG;

@@ -191,6 +191,69 @@ class TransformerLM(_BlocksLM):
         return self._p > 0.0
 
 
+    # ------------------------------------------------------------------ KV-cached decoding
+    @torch.no_grad()
+    def _decode_weights(self):
+        from . import sublayers as S
+        wp = S.OnTheFlyWeights(self.act_dtype)
+        ws = []
+        for blk in self.blocks:
+            heads = list(blk.sa_head.heads)
+            wqkv = torch.cat([h.query.weight for h in heads] + [h.key.weight for h in heads] + [h.value.weight for h in heads], 0)
+            ws.append(dict(ln1w=blk.ln1.weight, ln1b=blk.ln1.bias, wqkv=wp.fwd(wqkv), wproj=wp.fwd(blk.sa_head.proj.weight),
+                           bproj=blk.sa_head.proj.bias, ln2w=blk.ln2.weight, ln2b=blk.ln2.bias, w1=wp.fwd(blk.ffwd.net[0].weight),
+                           b1=blk.ffwd.net[0].bias, w2=wp.fwd(blk.ffwd.net[2].weight), b2=blk.ffwd.net[2].bias))
+        return ws, wp.fwd(self.lm_head.weight)
+
+    @torch.no_grad()
+    def _decode_step(self, tok_col, t, caches, ws, w_lm):
+        """logits (B, V) of the token at position t; K/V of position t are appended to the caches."""
+        act = self.act_dtype
+        B = tok_col.shape[0]
+        NH = len(self.blocks[0].sa_head.heads)
+        H = self.blocks[0].sa_head.heads[0].head_size
+        x = ops.embed_fwd(tok_col, self.token_embedding_table.weight, self.position_embedding_table.weight[t:t + 1]).view(B, -1)
+        for W, cache in zip(ws, caches):
+            h, _, _ = ops.layernorm_fwd(x, W["ln1w"], W["ln1b"], act)
+            ops.gemm_nt(h, W["wqkv"], act, out=cache[:, t])                       # q/k/v row t straight into the cache
+            o = ops.attn_decode(cache, t, NH, H, H ** -0.5)
+            x = ops.gemm_nt(o, W["wproj"], torch.float32, bias=W["bproj"], residual=x)
+            h, _, _ = ops.layernorm_fwd(x, W["ln2w"], W["ln2b"], act)
+            f = ops.gemm_nt(h, W["w1"], act, bias=W["b1"], relu=True)
+            x = ops.gemm_nt(f, W["w2"], torch.float32, bias=W["b2"], residual=x)
+        xa = x if act == torch.float32 else ops.cast(x, act)
+        return ops.gemm_nt(xa, w_lm, torch.float32, bias=self.lm_head.bias)
+
+    def generate(self, idx, max_new_tokens, generator: Optional[torch.Generator] = None, use_cache: bool = True):
+        """ref: src/model.py:611-636.  While the sequence still fits the context window the per-layer K/V of the
+        tokens seen so far are kept (training layout, [B, ctx, 3C]) and only the new position is computed; once the
+        window starts to slide every position embedding shifts, the cache is void, and decoding continues exactly
+        as the reference does (full forward on the cropped window).  Dropout is off in both paths only in eval()
+        mode -- like the reference, train() mode samples with dropout through the uncached path."""
+        if not use_cache or self.training or idx.shape[1] >= self.context_length:
+            return super().generate(idx, max_new_tokens, generator)
+        B, t0 = idx.shape
+        C3 = 3 * self.token_embedding_table.weight.shape[1]
+        ws, w_lm = self._decode_weights()
+        caches = [torch.zeros((B, self.context_length, C3), dtype=self.act_dtype, device=idx.device) for _ in self.blocks]
+        logits = None
+        for t in range(t0):                                      # prefill, one position at a time
+            logits = self._decode_step(idx[:, t:t + 1].contiguous(), t, caches, ws, w_lm)
+        produced = 0
+        while produced < max_new_tokens:
+            probs = ops.softmax_rows(logits)
+            nxt = torch.multinomial(probs.cpu(), num_samples=1, generator=generator).to(idx.device)
+            idx = torch.cat((idx, nxt), dim=1)
+            produced += 1
+            if produced == max_new_tokens:
+                break
+            t = idx.shape[1] - 1
+            if t >= self.context_length:                         # window slides: fall back to the reference algorithm
+                return super().generate(idx, max_new_tokens - produced, generator)
+            logits = self._decode_step(nxt.contiguous(), t, caches, ws, w_lm)
+        return idx
+
+
 MODEL_CLASSES = OrderedDict(
     BigramLM=BigramLM,
     SingleHeadAttentionLM=SingleHeadAttentionLM,

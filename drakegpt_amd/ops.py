@@ -295,6 +295,17 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, T: int
     return dqkv
 
 
+def attn_decode(cache: Tensor, t: int, NH: int, H: int, scale: float) -> Tensor:
+    """cache [B, Tcap, 3*NH*H]; returns the attention output of position t, [B, NH*H]."""
+    _chk(cache, "cache")
+    B, Tcap, W = cache.shape
+    if W != 3 * NH * H:
+        raise RuntimeError("attn_decode: cache width != 3*NH*H")
+    out = torch.empty((B, NH * H), dtype=cache.dtype, device=cache.device)
+    check(lib.dg_attn_decode(_p(cache), _p(out), B, Tcap, t, NH, H, float(scale), dt_code(cache.dtype), _stream()), "dg_attn_decode")
+    return out
+
+
 def cross_entropy(logits: Tensor, targets: Tensor, V: int, dlogits: Optional[Tensor] = None, grad_scale: float = 1.0,
                   grad_scale_dev: Optional[Tensor] = None, loss_rows: Optional[Tensor] = None) -> Tensor:
     _chk(logits, "logits", torch.float32, contiguous=False)

@@ -176,6 +176,14 @@ int dg_attn_bwd(const void* qkv, const void* out, const void* dout, const float*
                 float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
                 int dtype, void* stream);
 
+/* Single-query attention against a K/V cache for generate() -- ref: src/model.py:625-635 re-runs the
+ * whole forward per new token; with the cache only the new position is computed.  qkv_cache:
+ * [B, Tcap, 3*NH*H] in the training layout (row = position; the QKV GEMM of the new token writes row t);
+ * out [B, NH*H] = attention output of query row t over keys 0..t.  Same arithmetic and order as the
+ * generic forward kernel, so fp32 decoding is bit-identical to the uncached forward. */
+int dg_attn_decode(const void* qkv_cache, void* out, int B, int Tcap, int t, int NH, int H,
+                   float scale, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Cross entropy, mean over rows -- ref: F.cross_entropy at src/model.py:604-607 (K16).
  * loss_rows[m] = logsumexp(logits[m,:]) - logits[m,target[m]].  If dlogits != NULL also writes

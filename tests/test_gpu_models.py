@@ -164,3 +164,25 @@ def test_cpu_input_fails_loudly():
     m = D.BigramLM(V)
     with pytest.raises(RuntimeError, match="GPU"):
         m(torch.zeros((1, 4), dtype=torch.long))
+
+
+def test_kv_cached_generate_equals_uncached(dev):
+    """scaled-like shape, ctx 64: cached decoding == the reference algorithm (full forward per token), token for
+    token, including the hand-over to the uncached path when the window starts to slide."""
+    import drakegpt_amd as D
+    torch.manual_seed(0)
+    m = D.TransformerLM(V, 64, 24, 4, 2, 0.1).to(dev).eval()
+    start = torch.zeros((2, 3), dtype=torch.long, device=dev)
+    torch.manual_seed(11)
+    a = m.generate(start, 40, use_cache=False)
+    torch.manual_seed(11)
+    b = m.generate(start, 40, use_cache=True)
+    assert a.shape == (2, 43) and torch.equal(a, b)
+    # logits of the cached step equal the uncached forward's last row bit for bit (fp32 mode)
+    ws, w_lm = m._decode_weights()
+    caches = [torch.zeros((2, 24, 3 * 64), device=dev) for _ in m.blocks]
+    seq = a[:, :10].contiguous()
+    for t in range(10):
+        lg = m._decode_step(seq[:, t:t + 1].contiguous(), t, caches, ws, w_lm)
+    full, _ = m(seq)
+    assert torch.equal(lg, full[:, -1, :])
