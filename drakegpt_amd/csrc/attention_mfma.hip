@@ -217,29 +217,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnP p) {
 }
 
 // =============================================================================================
-// delta[b,h,i] = sum_d dO[i,d] * O[i,d]
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, float* __restrict__ delta,
-                                  int B, int T, int NH) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (b, t, h) with h fastest
-    const int64_t n = (int64_t)B * T * NH;
-    if (gid >= n) return;
-    const int h = (int)(gid % NH);
-    const int64_t bt = gid / NH;
-    const int64_t t = bt % T, b = bt / T;
-    const bf16_t* o = out + bt * (NH * HD) + h * HD;
-    const bf16_t* g = dout + bt * (NH * HD) + h * HD;
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        bf16x8 a = __builtin_bit_cast(bf16x8, *(const u32x4*)(o + 8 * i));
-        bf16x8 d = __builtin_bit_cast(bf16x8, *(const u32x4*)(g + 8 * i));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)d[j];
-    }
-    delta[(b * NH + h) * T + t] = s;
-}
-
-// =============================================================================================
 // dQ: wave = 32 queries; per key tile: S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T
 #define WAVE_LDS_DQ 12288
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnP p) {
@@ -266,7 +243,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnP p) {
     frags_global(qf, Qb, ld, q0, T, lane);
     frags_global(gf, dOb, C, q0, T, lane);
     const float L2 = (qi < T) ? p.lse_r[bh * T + qi] * LOG2E : 0.f;
-    const float dl = (qi < T) ? p.delta_r[bh * T + qi] : 0.f;
+    // delta_i = sum_d dO[i,d] O[i,d]: this lane holds half of row i of dO as MFMA fragments; dot it with the
+    // matching half of O and add the other half-wave's part.  Written out for the dK/dV pass that follows.
+    float dl = 0.f;
+    {
+        bf16x8 of[4];
+        frags_global(of, p.out + (int64_t)b * T * C + h * HD, C, q0, T, lane);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += (float)gf[ks][j] * (float)of[ks][j];
+        dl += __shfl_xor(dl, 32, 64);
+        if (hh == 0 && qi < T) p.delta[bh * T + qi] = dl;
+    }
     f32x16 dQ[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dQ[0][i] = 0.f; dQ[1][i] = 0.f; }
@@ -456,9 +445,6 @@ int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const f
     fill(p, B, T, NH, scale, dp, rng, site);
     p.qkv = (const bf16_t*)qkv; p.out = (const bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv;
     p.lse_r = lse; p.delta = delta; p.delta_r = delta;
-    const int64_t n = (int64_t)B * T * NH;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p.out, p.dout, delta, B, T, NH);
-    DG_LAUNCH_CHECK();
     dim3 grid((unsigned)((p.n_items + 3) / 4)), block(256);
     hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, block, 4 * WAVE_LDS_DQ, s, p);
     DG_LAUNCH_CHECK();
