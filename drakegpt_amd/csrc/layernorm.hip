@@ -199,27 +199,27 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const float
                 }
             }
         }
-        // combine the waves' column partials
-        float* lg = lds;               // [NW][C]
-        float* lb = lds + NW * C;      // [NW][C]
-        float* lq = lds + 2 * NW * C;  // [NW][C]  (FUSE_G)
+        // combine the waves' column partials through ONE [NW][C] LDS array, reused for dgamma, dbeta and
+        // (FUSE_G) the bias partials, so 16 waves per workgroup still fit the 64 KB dynamic-LDS default
+        float* lx = lds;
+        auto combine = [&](const f32x4 (&part)[LN_MAXV], float* dst) {
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
-            int i = lane + k * 64;
-            if (i < nv) {
-                *(f32x4*)(lg + w * C + i * 4) = dg[k]; *(f32x4*)(lb + w * C + i * 4) = db[k];
-                if (FUSE_G) *(f32x4*)(lq + w * C + i * 4) = gb[k];
+            for (int k = 0; k < LN_MAXV; ++k) {
+                int i = lane + k * 64;
+                if (i < nv) *(f32x4*)(lx + w * C + i * 4) = part[k];
             }
-        }
-        __syncthreads();
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            float a = 0.f, b = 0.f, q = 0.f;
+            __syncthreads();
+            for (int c = threadIdx.x; c < C; c += blockDim.x) {
+                float a = 0.f;
 #pragma unroll
-            for (int k = 0; k < NW; ++k) { a += lg[k * C + c]; b += lb[k * C + c]; if (FUSE_G) q += lq[k * C + c]; }
-            dgamma_part[(int64_t)blockIdx.x * part_stride + c] = a;
-            dbeta_part[(int64_t)blockIdx.x * part_stride + c] = b;
-            if (FUSE_G) fz.gbias_part[(int64_t)blockIdx.x * part_stride + c] = q;
-        }
+                for (int k = 0; k < NW; ++k) a += lx[k * C + c];
+                dst[(int64_t)blockIdx.x * part_stride + c] = a;
+            }
+            __syncthreads();
+        };
+        combine(dg, dgamma_part);
+        combine(db, dbeta_part);
+        if (FUSE_G) combine(gb, fz.gbias_part);
     } else {
         // generic path: any C; column partials accumulate directly in LDS [2][NW][C] per wave
         float* lg = lds; float* lb = lds + NW * C;
@@ -266,8 +266,7 @@ static int ln_bwd_launch(LnFuse fz, int fuse, const float* dy, const float* x, c
     if (fuse && (!vec || nk > 4 || !fz.g || !fz.gbias_part || !dg_aligned16(fz.g))) return DG_ERR_ARG;
     // more waves per workgroup = more rows in flight per partial (HBM-bound: needs the occupancy)
     int nthreads = C <= 512 ? 1024 : (C <= 1024 ? 512 : 256);
-    if (fuse && nthreads == 1024) nthreads = 512;           // a third [NW][C] LDS array: stay under 64 KB
-    size_t lds_bytes = (size_t)(fuse ? 3 : 2) * (nthreads / 64) * C * sizeof(float);
+    size_t lds_bytes = (size_t)2 * (nthreads / 64) * C * sizeof(float);    // (the vector path uses half of it)
     int rows_per = (M + n_partials - 1) / n_partials;
     dim3 grid(n_partials), block(nthreads);
     hipStream_t s = (hipStream_t)stream;
@@ -281,10 +280,10 @@ static int ln_bwd_launch(LnFuse fz, int fuse, const float* dy, const float* x, c
         else if (nk == 4) LAUNCH(true, 4, 512, 0);
         else LAUNCH(true, 8, 256, 0);
     } else if (fuse == 1) {
-        if (nk <= 1) LAUNCH(true, 1, 512, 1); else if (nk == 2) LAUNCH(true, 2, 512, 1);
+        if (nk <= 1) LAUNCH(true, 1, 1024, 1); else if (nk == 2) LAUNCH(true, 2, 1024, 1);
         else if (nk == 3) LAUNCH(true, 3, 512, 1); else LAUNCH(true, 4, 512, 1);
     } else {
-        if (nk <= 1) LAUNCH(true, 1, 512, 2); else if (nk == 2) LAUNCH(true, 2, 512, 2);
+        if (nk <= 1) LAUNCH(true, 1, 1024, 2); else if (nk == 2) LAUNCH(true, 2, 1024, 2);
         else if (nk == 3) LAUNCH(true, 3, 512, 2); else LAUNCH(true, 4, 512, 2);
     }
 #undef LAUNCH
