@@ -64,13 +64,21 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    # rehearsal hook for a 1-GPU box: DG_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and moves the gradient
+    # over gloo (RCCL refuses two ranks on one device); the driver's multi-GPU runs use one GPU per rank + RCCL
+    share = os.environ.get("DG_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         pg = dist.group.WORLD
 
     import drakegpt_amd as D
@@ -99,7 +107,10 @@ def main():
     def barrier():
         if world > 1:
             import torch.distributed as dist
-            dist.barrier(device_ids=[local_rank])
+            if share:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize(dev)
 
     if rank == 0:
@@ -153,9 +164,10 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
+        barrier()                      # rank 0 did the kernel-timing leg: leave together
         dist.destroy_process_group()
 
 

@@ -301,3 +301,42 @@ def test_transpose_cast_batched(dev):
             R = W.shape[0]
             assert torch.equal(Wt[:, :R].cpu(), W.T.to(dt).cpu())
             assert torch.all(Wt[:, R:] == 0)
+
+
+def test_argument_validation_rejects_before_launch(dev):
+    """bad shapes / alignment / dtypes come back as DG_ERR_* from the C ABI (no kernel is launched)."""
+    import ctypes as C
+    from drakegpt_amd import _lib
+    ops = _ops()
+    lib = _lib.lib
+    x = torch.zeros(64, 40, device=dev)
+    a = _lib.GemmNtArgs()
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = x.data_ptr(), 40, x.data_ptr(), 40, x.data_ptr(), 64
+    a.M, a.N, a.K, a.in_dtype, a.out_dtype = 64, 64, 38, _lib.DG_F32, _lib.DG_F32
+    assert lib.dg_gemm_nt(C.byref(a), None) == -2                    # K not a multiple of 4 floats: DG_ERR_ALIGN
+    a.K, a.in_dtype = 40, 7
+    assert lib.dg_gemm_nt(C.byref(a), None) == -3                    # DG_ERR_DTYPE
+    a.in_dtype, a.M = _lib.DG_F32, 0
+    assert lib.dg_gemm_nt(C.byref(a), None) == -1                    # DG_ERR_ARG
+    assert lib.dg_attn_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 8, 1, 300, 1.0, 0.0, None, 0, _lib.DG_F32, None) == -1
+    assert lib.dg_layernorm_fwd(None, x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, x.data_ptr(), x.data_ptr(), 4, 40, 1e-5, None) == -1
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        _lib.check(-1, "probe")
+    with pytest.raises(TypeError):
+        ops.gemm_nt(x, x.bfloat16(), torch.float32)                  # operand dtypes differ
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.cast(torch.zeros(4), torch.bfloat16)                     # CPU tensor: no fallback
+
+
+def test_engine_minimal_shapes(dev):
+    """B = 1, T = 1 (softmax over one key, single-row GEMMs) through the graph-captured engine, both precisions."""
+    import drakegpt_amd as D
+    from drakegpt_amd.engine import TrainEngine
+    for precision in ("fp32", "bf16"):
+        torch.manual_seed(1)
+        m = D.TransformerLM(80, 64, 8, 1, 1, 0.5, precision=precision).to(dev)
+        eng = TrainEngine(m, 1, 1, lr=1e-3)
+        eng.set_batch(torch.tensor([[3]], device=dev), torch.tensor([[5]], device=dev))
+        l0 = eng.step().item()
+        l1 = eng.step().item()
+        assert l0 > 0 and l1 > 0 and l0 == l0 and l1 == l1
