@@ -132,7 +132,7 @@ __device__ __forceinline__ void store_N_acc(char* img, const f32x16 (&acc)[2], f
 
 #define WAVE_LDS_FWD 8192
 // =============================================================================================
-__global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(AttnP p) {
 // =============================================================================================
 // dQ: wave = 32 queries; per key tile: S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T
 #define WAVE_LDS_DQ 12288
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t item = (int64_t)blockIdx.x * 4 + wave;
