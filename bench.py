@@ -190,7 +190,7 @@ def kernel_roofline(eng, offsets, peak_tflops):
         r = real_nt(A, Bm, out_dtype, **kw)
         to = "bf16" if out_dtype == torch.bfloat16 else "float"
         if A.dtype == torch.bfloat16 and K % 64 == 0 and K >= 128:        # dispatch rule of dg_gemm_nt
-            sym = f"gemm_nt_pers_kernel<{to}>"
+            sym = f"gemm_nt_ws_kernel<{to}>"
         else:
             sym = f"gemm_nt_kernel<{'bf16' if A.dtype == torch.bfloat16 else 'float'},{to}>"
         kw2 = dict(kw)

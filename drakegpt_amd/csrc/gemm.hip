@@ -320,6 +320,210 @@ __global__ __launch_bounds__(512) void gemm_nt_glds_kernel(NtParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wave-specialised form of the persistent kernel below: 8 MFMA waves + 4 loader waves per workgroup.
+// In the unspecialised kernel every wave pays ~300 cycles per K step to issue its 4 LDS-DMA pieces (an
+// in-order wave cannot issue MFMAs meanwhile) plus a counted vmcnt wait; here the loaders run one
+// barrier phase ahead of the MFMA waves, which execute nothing but LDS reads, MFMAs and the epilogue.
+// Both roles execute the same barrier sequence (prologue + one per global K step).
+// (shared description) one workgroup per CU walks its tiles with ONE continuous
+// stage pipeline -- the first stages of the next tile are already in flight while the current tile
+// finishes, so the per-tile prologue (HBM/L2 latency), epilogue and workgroup dispatch no longer
+// serialise (they dominated at K = 384: six K steps per tile).  The accumulators are kept
+// TRANSPOSED (mfma(B, A)): a lane then owns 4 consecutive output columns of one row, so the
+// epilogue stores 8/16-byte pieces straight from registers and needs no LDS staging at all.
+template <typename TO>
+__global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE + 8 * 4096];   // 4 stages + a 4 KB epilogue slice per wave = 160 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int G = gridDim.x;
+    const int my_tiles = (p.n_tiles - (int)blockIdx.x + G - 1) / G;
+    const int nk = p.K / 64;
+    const int total = my_tiles * nk;
+
+    const int prow = lane >> 3, slot = lane & 7;
+    const int chunk = slot ^ prow;
+    const bool loader = wave >= 8;                 // waves 8..11 only move data
+    const int lw = wave - 8;
+    const char* srcA[4];
+    const char* srcB[4];
+    auto set_src = [&](int ti) {
+        const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
+        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (4 * lw + i) * 8 + prow;
+            int gm = m0 + row; if (gm > p.M - 1) gm = p.M - 1;
+            int gn = n0 + row; if (gn > p.N - 1) gn = p.N - 1;
+            srcA[i] = p.A + (int64_t)gm * p.lda_b + chunk * 16;
+            srcB[i] = p.B + (int64_t)gn * p.ldb_b + chunk * 16;
+        }
+    };
+    int iss_tile = 0, iss_kt = 0;
+    auto issue = [&](int g) {
+        char* base = lds + (g & (GL_NST - 1)) * GL_STAGE + (4 * lw) * 1024;
+        const int64_t koff = (int64_t)iss_kt * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + koff), (lptr_t)(base + 16384 + i * 1024), 16, 0, 0);
+        }
+        if (++iss_kt == nk) { iss_kt = 0; if (++iss_tile < my_tiles) set_src(iss_tile); }
+    };
+    if (loader) {
+        // ---- loader role: 8 LDS-DMA pieces per stage per wave; stages g+1.. stay in flight behind counted waits
+        set_src(0);
+        const int npre = total < GL_NST - 1 ? total : GL_NST - 1;
+        for (int g = 0; g < npre; ++g) issue(g);
+        if (npre >= 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (npre == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // stage 0 published
+        for (int g = 0; g + 1 < total; ++g) {
+            int issued = g + GL_NST - 1; if (issued > total) issued = total;
+            if (issued - (g + 2) >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage g+1 landed, g+2 may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                          // publishes stage g+1; stage g-1's buffer is free
+            if (g + GL_NST - 1 < total) issue(g + GL_NST - 1);
+        }
+        return;
+    }
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    auto read_frags = [&](u32x4 (&fa)[2], u32x4 (&fb)[4], const char* buf, int ks) {
+        const int ka = nt_lds_off(wm * 32 + fr, ks * 4 + fg), kb = nt_lds_off(wn * 64 + fr, ks * 4 + fg);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(buf + ka + i * 16 * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(buf + 16384 + kb + j * 16 * 128);
+    };
+    auto mma_all = [&](const u32x4 (&fa)[2], const u32x4 (&fb)[4]) {      // transposed: D rows = n, cols = m
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
+    };
+    uint32_t key = 0;
+    if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
+    TO* Cp = (TO*)p.C;
+    // Epilogue: the transposed accumulators (lane = row fr, 4 consecutive columns per (i,j)) are
+    // passed through a wave-private 16 x 64 fp32 LDS slice (XOR-swizzled 16-byte chunks) and read
+    // back by rows, so one store instruction covers 4 whole rows (4-8 full cache lines) instead of
+    // 16 partial ones -- the stores were transaction-bound, not byte-bound.
+    float* stage = (float*)(lds + GL_NST * GL_STAGE + wave * 4096);
+    auto epilogue = [&](int ti) -> bool {
+        const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
+        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+        const bool interior = p.vec_ok && (m0 + BM <= p.M) && (n0 + BN <= p.N) && p.dbg == 0;
+        const int ch = lane & 15;                              // 16-byte chunk = 4 columns
+        const int col = n0 + wn * 64 + ch * 4;
+        const bool full = p.vec_ok && (col + 3 < p.N);
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && col < p.N) {
+            if (full) bv = *(const f32x4*)(p.bias + col);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *(f32x4*)(stage + fr * 64 + (((j * 4 + fg) ^ fr) << 2)) = acc[i][j];
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int lrow = it * 4 + (lane >> 4);
+                const int row = m0 + wm * 32 + i * 16 + lrow;
+                f32x4 v = *(const f32x4*)(stage + lrow * 64 + ((ch ^ lrow) << 2));
+                if (row >= p.M || col >= p.N) continue;
+                if (p.dbg >= 3 && v[0] != 12345.678f) continue;      // ablation: no stores
+                v += bv;
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (p.relu_mask) {
+                    const bf16_t* mp = (const bf16_t*)p.relu_mask + (int64_t)row * p.ldmask + col;
+                    if (full && p.mask_vec_ok) {
+                        const bf16x4 mk = *(const bf16x4*)mp;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col + e < p.N) v[e] = (float)mp[e] > 0.f ? v[e] : 0.f;
+                    }
+                }
+                if (p.drop) {
+                    const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
+                }
+                if (p.residual) {
+                    const float* rp = p.residual + (int64_t)row * p.ldr + col;
+                    if (full) v += *(const f32x4*)rp;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col + e < p.N) v[e] += rp[e];
+                    }
+                }
+                TO* cp = Cp + (int64_t)row * p.ldc + col;
+                if (full) {
+                    if (sizeof(TO) == 4) *(f32x4*)cp = v;
+                    else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+                        *(bf16x4*)cp = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < p.N) cp[e] = from_f32<TO>(v[e]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return interior;
+    };
+
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (p.stamps && tid == 0 && nstamp < 64) p.stamps[(size_t)blockIdx.x * 64 + nstamp] = __builtin_amdgcn_s_memtime();
+        ++nstamp;
+    };
+    stamp();
+    // ---- MFMA role
+    u32x4 fa0[2], fb0[4], fa1[2], fb1[4];
+    __builtin_amdgcn_s_barrier();                                  // stage 0 published by the loaders
+    read_frags(fa0, fb0, lds, 0);
+    stamp();
+    int kt = 0, tile_i = 0;
+    for (int g = 0; g < total; ++g) {
+        const char* buf = lds + (g & (GL_NST - 1)) * GL_STAGE;
+        if (p.dbg != 2) { read_frags(fa1, fb1, buf, 1); mma_all(fa0, fb0); }
+        if (g + 1 < total) {
+            __builtin_amdgcn_s_barrier();                          // stage g+1 is visible; nothing to wait for here
+            if (p.dbg != 2) read_frags(fa0, fb0, lds + ((g + 1) & (GL_NST - 1)) * GL_STAGE, 0);
+        }
+        if (p.dbg != 2) mma_all(fa1, fb1);
+        stamp();
+        if (++kt == nk) { epilogue(tile_i); kt = 0; ++tile_i; stamp(); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Persistent form of the LDS-DMA kernel: one workgroup per CU walks its tiles with ONE continuous
 // stage pipeline -- the first stages of the next tile are already in flight while the current tile
 // finishes, so the per-tile prologue (HBM/L2 latency), epilogue and workgroup dispatch no longer
@@ -520,8 +724,8 @@ static unsigned long long* g_stamp_buffer = nullptr;
 // diagnostic only (tools/gemm_stamps.py): not part of the public header
 extern "C" void dg_debug_set_stamp_buffer(void* p) { g_stamp_buffer = (unsigned long long*)p; }
 
-// bf16 NT variant switch for A/B benchmarking: DG_GEMM_NT = 0 persistent LDS-DMA (default),
-// 1 register-staged, 2 LDS-DMA one tile per workgroup
+// bf16 NT variant switch for A/B benchmarking: DG_GEMM_NT = 0 wave-specialised persistent LDS-DMA (default),
+// 1 register-staged, 2 LDS-DMA one tile per workgroup, 4 persistent LDS-DMA without loader waves
 static int dg_nt_mode() {
     static const int v = [] { const char* e = getenv("DG_GEMM_NT"); return e ? atoi(e) : 0; }();
     return v;
@@ -571,10 +775,14 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
     p.n_tiles = tiles_m * p.tiles_n;
     dim3 grid(p.n_tiles), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 0) {
+    if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 4) {
         dim3 pgrid(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
         if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_pers_kernel<bf16_t>), pgrid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_nt_pers_kernel<float>), pgrid, dim3(512), 0, s, p);
+    } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 0) {
+        dim3 pgrid(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
+        if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t>), pgrid, dim3(768), 0, s, p);
+        else hipLaunchKernelGGL((gemm_nt_ws_kernel<float>), pgrid, dim3(768), 0, s, p);
     } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 2) {
         if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16_t>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_nt_glds_kernel<float>), grid, dim3(512), 0, s, p);
