@@ -1025,6 +1025,121 @@ __global__ __launch_bounds__(512) void gemm_tn_glds_kernel(TnParams p) {
     }
 }
 
+// ---- bf16, wave-specialised LDS-DMA form (as gemm_nt_ws_kernel): 8 MFMA waves (4 x 2 of 32 x 64) + 4 loader waves
+// ---- (description of the shared structure:) 8 waves (4 x 2 of 32 x 64), 4 stages of [64 r][128 cols] x 2 operands,
+//      global_load_lds writes image (b) directly (per-lane SOURCE chunk = slot ^ f(row)), counted
+//      vmcnt + one raw barrier per K step, fragments of the next half step always in flight.
+//      Requires whole 64-row steps (R % 64 == 0); column tails read clamped (finite) data that only
+//      reaches outputs which are not stored.  Accumulators transposed (mfma(B, A)): 16-byte stores.
+__global__ __launch_bounds__(768) void gemm_tn_ws_kernel(TnParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wq = wave & 1;
+    int tile, split;
+    tn_work(p, tile, split);
+    if (tile >= p.n_tiles) return;                          // padding of the 1-D grid (whole workgroup)
+    const int p0 = (tile / p.tiles_q) * 128, q0 = (tile % p.tiles_q) * 128;
+    const int r_begin = split * p.r_per_split;
+    int r_end = r_begin + p.r_per_split; if (r_end > p.R) r_end = p.R;
+    const int nk = r_end > r_begin ? (r_end - r_begin) / 64 : 0;
+
+    // piece = 1 KB = 4 rows x 256 B; this wave moves pieces 2w, 2w+1 of A and of B per stage
+    const int prow = lane >> 4, slot = lane & 15;
+    const bool loader = wave >= 8;
+    const int lw = wave - 8;
+    const char* srcA[4];
+    const char* srcB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = 4 * (loader ? lw : 0) + i;
+        const int row = 4 * q + prow;
+        const int chunk = slot ^ ((prow << 2) | (q & 3));           // f(row) of image (b): ((row&3)<<2)|((row>>2)&3)
+        int ca = p0 + chunk * 8; if (ca + 8 > p.lda_b / 2) ca = 0;   // past the leading dimension: clamp
+        int cb = q0 + chunk * 8; if (cb + 8 > p.ldb_b / 2) cb = 0;
+        srcA[i] = p.A + (int64_t)(r_begin + row) * p.lda_b + (int64_t)ca * 2;
+        srcB[i] = p.B + (int64_t)(r_begin + row) * p.ldb_b + (int64_t)cb * 2;
+    }
+    auto issue = [&](int kt) {
+        char* base = lds + (kt & (GL_NST - 1)) * GL_STAGE + (4 * lw) * 1024;
+        const int64_t ra = (int64_t)kt * 64 * p.lda_b, rb = (int64_t)kt * 64 * p.ldb_b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + ra), (lptr_t)(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + rb), (lptr_t)(base + 16384 + i * 1024), 16, 0, 0);
+        }
+    };
+    if (loader) {
+        if (nk > 0) {
+            const int npre = nk < GL_NST - 1 ? nk : GL_NST - 1;
+            for (int g = 0; g < npre; ++g) issue(g);
+            if (npre >= 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (npre == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int g = 0; g + 1 < nk; ++g) {
+                int issued = g + GL_NST - 1; if (issued > nk) issued = nk;
+                if (issued - (g + 2) >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (g + GL_NST - 1 < nk) issue(g + GL_NST - 1);
+            }
+        }
+        return;
+    }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    auto read_frags = [&](u32x4 (&fa)[2], u32x4 (&fb)[4], const char* buf, int ks) {
+        const int r0 = ks * 32 + fg * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = tn_frag_bf16(buf, r0, wp * 32 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = tn_frag_bf16(buf + 16384, r0, wq * 64 + j * 16, lane);
+    };
+    auto mma_all = [&](const u32x4 (&fa)[2], const u32x4 (&fb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
+    };
+    if (nk > 0) {
+        u32x4 fa0[2], fb0[4], fa1[2], fb1[4];
+        __builtin_amdgcn_s_barrier();                              // stage 0 published by the loaders
+        read_frags(fa0, fb0, lds, 0);
+        for (int g = 0; g < nk; ++g) {
+            const char* buf = lds + (g & (GL_NST - 1)) * GL_STAGE;
+            read_frags(fa1, fb1, buf, 1);
+            mma_all(fa0, fb0);
+            if (g + 1 < nk) {
+                __builtin_amdgcn_s_barrier();
+                read_frags(fa0, fb0, lds + ((g + 1) & (GL_NST - 1)) * GL_STAGE, 0);
+            }
+            mma_all(fa1, fb1);
+        }
+    }
+    float* out = p.out + (int64_t)split * p.split_stride;
+    const bool vec = (p.ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = p0 + wp * 32 + i * 16 + fr;
+        if (row >= p.P) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = q0 + wq * 64 + j * 16 + 4 * fg;
+            float* op = out + (int64_t)row * p.ldo + col;
+            if (vec && col + 3 < p.Q) *(f32x4*)op = acc[i][j];
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < p.Q) op[e] = acc[i][j][e];
+            }
+        }
+    }
+}
+
 // ---- f32: [32 r][128 cols] tiles with 144-float row pitch (pad 16 floats: rows r, r+1 of one
 //      ds_read_b32 half-wave land on different banks)
 #define TNF_PITCH 144
@@ -1139,7 +1254,9 @@ extern "C" int dg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
     // the LDS-DMA kernel owns a CU (128 KB LDS): use it when the launch fits one wave of workgroups,
     // otherwise two register-staged workgroups per CU finish sooner than a second round
     const bool one_round = (int64_t)p.n_tiles * n_splits <= dg_num_cus();
-    if (dtype == DG_BF16 && R % 64 == 0 && (tn_mode == 2 || (tn_mode == 0 && one_round)))
+    if (dtype == DG_BF16 && R % 64 == 0 && (tn_mode == 3 || (tn_mode == 0 && one_round)))
+        hipLaunchKernelGGL(gemm_tn_ws_kernel, grid, dim3(768), 0, s, p);
+    else if (dtype == DG_BF16 && R % 64 == 0 && tn_mode == 2)
         hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, dim3(512), 0, s, p);
     else if (dtype == DG_BF16) hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, block, 0, s, p);
     else hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, block, 0, s, p);

@@ -74,7 +74,9 @@ class FlatSink:
     def matrix(self, key, P, Q):
         off, shape = self.e.layA.entries[key]
         assert shape == (P, Q), (key, shape, P, Q)
-        return self.e.slabs[0, off:off + P * Q], self.e.layA.size, self.e.S
+        # slabs beyond this matrix's own split count are never written: they stay zero from allocation
+        n = S.splits_for_matrix(P, Q, self.e.M, self.e.S, self.e.dev)
+        return self.e.slabs[0, off:off + P * Q], self.e.layA.size, n
 
     def vector(self, key, N):
         off, shape = self.e.layB.entries[key]

@@ -53,6 +53,20 @@ def n_splits_for(rows: int) -> int:
     return max(1, min(8, rows // 2048))
 
 
+_NCU = {}
+
+
+def splits_for_matrix(P: int, Q: int, rows: int, s_max: int, device=None) -> int:
+    """Per-matrix split count of a dW GEMM: as many splits as still give ONE round of workgroups
+    (tiles * splits <= #CUs; the LDS-DMA kernel owns a CU), never more than the slab count s_max.
+    FFN weights at the scaled config: 36 tiles -> 7 splits (30 us) instead of 8 (two rounds, 46 us)."""
+    key = str(device)
+    if key not in _NCU:
+        _NCU[key] = torch.cuda.get_device_properties(device).multi_processor_count if torch.cuda.is_available() else 256
+    tiles = ((P + 127) // 128) * ((Q + 127) // 128)
+    return max(1, min(s_max, _NCU[key] // tiles, max(1, rows // 256)))
+
+
 def n_partials_for(rows: int) -> int:
     """row-chunk partials of the column-sum style reductions (bias / LayerNorm gradients)"""
     return max(1, min(256, rows // 32))
@@ -78,6 +92,7 @@ class LocalSink:
     """Gradient sink of the autograd path: allocates partial buffers, reduces on `finish`."""
 
     def __init__(self, rows: int, device):
+        self.rows = rows
         self.S = n_splits_for(rows)
         self.G = n_partials_for(rows)
         self.device = device
@@ -85,9 +100,10 @@ class LocalSink:
         self._direct: Dict[str, Tensor] = {}
 
     def matrix(self, key: str, P: int, Q: int):
-        part = torch.empty((self.S, P, Q), dtype=torch.float32, device=self.device)
-        self._pending[key] = (part, P * Q, self.S, (P, Q))
-        return part, P * Q, self.S
+        n = splits_for_matrix(P, Q, self.rows, self.S, self.device)
+        part = torch.empty((n, P, Q), dtype=torch.float32, device=self.device)
+        self._pending[key] = (part, P * Q, n, (P, Q))
+        return part, P * Q, n
 
     def vector(self, key: str, N: int):
         part = torch.empty((self.G, N), dtype=torch.float32, device=self.device)

@@ -72,7 +72,7 @@ def main():
     if a.what in ("tn", "all"):
         print(f"-- gemm_tn (bf16), R={M}")
         for name, P, Q in (("dWqkv", 3 * C, C), ("dW1", 4 * C, C), ("dW2", C, 4 * C), ("dWproj", C, C), ("dWlm", V, C)):
-            for S in (1, 2, 4, 8):
+            for S in (1, 2, 4, 5, 6, 7, 8):
                 A, Bm = rnd(M, P), rnd(M, Q)
                 part = torch.empty(S, P, Q, device=dev)
                 t = timeit(lambda: ops.gemm_tn(A, Bm, part, P * Q, S, P, Q))
