@@ -202,7 +202,7 @@ def kernel_roofline(eng, offsets, peak_tflops):
         real_tn(A, Bm, out_part, split_stride, n_splits, P, Q, ldo)
         tiles = ((P + 127) // 128) * ((Q + 127) // 128)
         if A.dtype == torch.bfloat16:                                          # dispatch rule of dg_gemm_tn
-            sym = "gemm_tn_glds_kernel" if (A.shape[0] % 64 == 0 and tiles * n_splits <= ncu) else "gemm_tn_bf16_kernel"
+            sym = "gemm_tn_ws_kernel" if (A.shape[0] % 64 == 0 and tiles * n_splits <= ncu) else "gemm_tn_bf16_kernel"
         else:
             sym = "gemm_tn_f32_kernel"
         calls.append((sym, 2.0 * A.shape[0] * P * Q, lambda: real_tn(A, Bm, out_part, split_stride, n_splits, P, Q, ldo)))

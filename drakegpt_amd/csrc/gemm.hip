@@ -24,6 +24,10 @@
 #define GL_STAGE 32768                        // ... of 32 KB (two 16 KB operand tiles)
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+#ifndef WS_NLOAD
+#define WS_NLOAD 4                            // loader waves of the wave-specialised kernels
+#endif
+#define WS_PPL (16 / WS_NLOAD)                // 1 KB LDS-DMA pieces per loader wave, per operand, per stage
 #define NT_LDS_BYTES (4 * 64 * EPI_PITCH * 4)  // 69632: four 64x68 fp32 staging slices >= the 4 x 16 KB operand buffers
 
 // ---------------------------------------------------------------------------------------------
@@ -345,14 +349,14 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     const int chunk = slot ^ prow;
     const bool loader = wave >= 8;                 // waves 8..11 only move data
     const int lw = wave - 8;
-    const char* srcA[4];
-    const char* srcB[4];
+    const char* srcA[WS_PPL];
+    const char* srcB[WS_PPL];
     auto set_src = [&](int ti) {
         const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
         const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (4 * lw + i) * 8 + prow;
+        for (int i = 0; i < WS_PPL; ++i) {
+            const int row = (WS_PPL * lw + i) * 8 + prow;
             int gm = m0 + row; if (gm > p.M - 1) gm = p.M - 1;
             int gn = n0 + row; if (gn > p.N - 1) gn = p.N - 1;
             srcA[i] = p.A + (int64_t)gm * p.lda_b + chunk * 16;
@@ -361,10 +365,10 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     };
     int iss_tile = 0, iss_kt = 0;
     auto issue = [&](int g) {
-        char* base = lds + (g & (GL_NST - 1)) * GL_STAGE + (4 * lw) * 1024;
+        char* base = lds + (g & (GL_NST - 1)) * GL_STAGE + (WS_PPL * lw) * 1024;
         const int64_t koff = (int64_t)iss_kt * 128;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < WS_PPL; ++i) {
             __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + i * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + koff), (lptr_t)(base + 16384 + i * 1024), 16, 0, 0);
         }
@@ -375,13 +379,13 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
         set_src(0);
         const int npre = total < GL_NST - 1 ? total : GL_NST - 1;
         for (int g = 0; g < npre; ++g) issue(g);
-        if (npre >= 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (npre == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (npre >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * WS_PPL) : "memory");
+        else if (npre == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * WS_PPL) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // stage 0 published
         for (int g = 0; g + 1 < total; ++g) {
             int issued = g + GL_NST - 1; if (issued > total) issued = total;
-            if (issued - (g + 2) >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage g+1 landed, g+2 may fly
+            if (issued - (g + 2) >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * WS_PPL) : "memory");   // stage g+1 landed, g+2 may fly
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                          // publishes stage g+1; stage g-1's buffer is free
             if (g + GL_NST - 1 < total) issue(g + GL_NST - 1);
@@ -781,8 +785,8 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
         else hipLaunchKernelGGL((gemm_nt_pers_kernel<float>), pgrid, dim3(512), 0, s, p);
     } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 0) {
         dim3 pgrid(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
-        if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t>), pgrid, dim3(768), 0, s, p);
-        else hipLaunchKernelGGL((gemm_nt_ws_kernel<float>), pgrid, dim3(768), 0, s, p);
+        if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t>), pgrid, dim3(512 + 64 * WS_NLOAD), 0, s, p);
+        else hipLaunchKernelGGL((gemm_nt_ws_kernel<float>), pgrid, dim3(512 + 64 * WS_NLOAD), 0, s, p);
     } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 2) {
         if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16_t>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_nt_glds_kernel<float>), grid, dim3(512), 0, s, p);
