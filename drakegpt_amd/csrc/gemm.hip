@@ -724,12 +724,205 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(NtParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// EXPERIMENT (DG_GEMM_NT=5 only; not used by default): 256 x 128 tile, 32-deep K steps, six 24 KB stages --
+// 25 % fewer operand bytes per FLOP than the 128 x 128 kernel, same wave specialisation.  Measured on the
+// training shapes it is 7-16 % SLOWER than the 128 x 128 kernel (QKV 35.0 vs 30.1 us, FFN1 41.5 vs 36.3) and
+// only 4 % faster at 4096^3: twice the barriers per 64 of K and half the workgroup rounds cost more than the
+// saved fill bytes.  Kept as the measured negative it is.
+// waves 0-7 = 4 x 2 MFMA waves of 64 x 64 (one v_mfma_f32_16x16x32_bf16 per 16 x 16 block and stage),
+// waves 8-11 = loaders, up to five stages (120 KB) in flight.  LDS rows are 64 B (4 chunks); chunk position
+// = chunk ^ (2 * ((row >> 3) & 1)), conflict-free for the 16-row x 2-chunk ds_read_b128 groups.  The epilogue
+// stores the transposed accumulators straight from registers (measured: the store shape does not matter).
+#define W2_NST 6
+#define W2_STAGE 24576                        // A 256 rows x 64 B + B 128 rows x 64 B
+__device__ __forceinline__ int w2_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) << 1)) << 4); }
+
+template <typename TO>
+__global__ __launch_bounds__(768) void gemm_nt_ws2_kernel(NtParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[W2_NST * W2_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x;
+    const int tiles_n = p.tiles_n;                              // 128-wide
+    const int tiles_m2 = (p.M + 255) / 256;
+    const int n_tiles2 = tiles_m2 * tiles_n;
+    const int my_tiles = (n_tiles2 - (int)blockIdx.x + G - 1) / G;
+    const int nk = p.K / 32;
+    const int total = my_tiles * nk;
+    auto tile_origin = [&](int ti, int& m0, int& n0) {
+        const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, n_tiles2);
+        m0 = (tile / tiles_n) * 256; n0 = (tile % tiles_n) * 128;
+    };
+    if (wave >= 8) {
+        // ------------------------------------------------------------------ loaders
+        const int lw = wave - 8;
+        const int prow = lane >> 2, slot = lane & 3;
+        const int chunk = slot ^ (((prow >> 3) & 1) << 1);
+        const char* srcA[4];
+        const char* srcB[2];
+        auto set_src = [&](int ti) {
+            int m0, n0;
+            tile_origin(ti, m0, n0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int gm = m0 + (4 * lw + i) * 16 + prow; if (gm > p.M - 1) gm = p.M - 1;
+                srcA[i] = p.A + (int64_t)gm * p.lda_b + chunk * 16;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int gn = n0 + (2 * lw + i) * 16 + prow; if (gn > p.N - 1) gn = p.N - 1;
+                srcB[i] = p.B + (int64_t)gn * p.ldb_b + chunk * 16;
+            }
+        };
+        int iss_tile = 0, iss_kt = 0;
+        auto issue = [&](int g) {
+            char* base = lds + (g % W2_NST) * W2_STAGE;
+            const int64_t koff = (int64_t)iss_kt * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + (4 * lw + i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + koff), (lptr_t)(base + 16384 + (2 * lw + i) * 1024), 16, 0, 0);
+            if (++iss_kt == nk) { iss_kt = 0; if (++iss_tile < my_tiles) set_src(iss_tile); }
+        };
+        auto wait_ahead = [&](int ahead) {                       // `ahead` younger stages (6 pieces each) may stay in flight
+            if (ahead >= 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (ahead == 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        set_src(0);
+        const int npre = total < W2_NST - 1 ? total : W2_NST - 1;
+        for (int g = 0; g < npre; ++g) issue(g);
+        wait_ahead(npre - 1);
+        __builtin_amdgcn_s_barrier();                              // stage 0 published
+        for (int g = 0; g + 1 < total; ++g) {
+            int issued = g + W2_NST - 1; if (issued > total) issued = total;
+            wait_ahead(issued - (g + 2));
+            __builtin_amdgcn_s_barrier();                          // publishes stage g+1; stage g-1's buffer is free
+            if (g + W2_NST - 1 < total) issue(g + W2_NST - 1);
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- MFMA waves
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int offA = w2_off(wm * 64 + fr, fg), offB = 16384 + w2_off(wn * 64 + fr, fg);     // +16 rows keep the swizzle
+    auto read_frags = [&](u32x4 (&fa)[4], u32x4 (&fb)[4], int g) {
+        const char* buf = lds + (g % W2_NST) * W2_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *(const u32x4*)(buf + offA + i * 16 * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(buf + offB + j * 16 * 64);
+    };
+    auto mma_all = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[4]) {      // transposed: D rows = n, cols = m
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
+    };
+    uint32_t key = 0;
+    if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
+    TO* Cp = (TO*)p.C;
+    auto epilogue = [&](int ti) {
+        int m0, n0;
+        tile_origin(ti, m0, n0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 64 + j * 16 + 4 * fg;
+            const bool full = p.vec_ok && (col + 3 < p.N);
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && col < p.N) {
+                if (full) bv = *(const f32x4*)(p.bias + col);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + wm * 64 + i * 16 + fr;
+                f32x4 v = acc[i][j] + bv;
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (row >= p.M || col >= p.N) continue;
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (p.relu_mask) {
+                    const bf16_t* mp = (const bf16_t*)p.relu_mask + (int64_t)row * p.ldmask + col;
+                    if (full && p.mask_vec_ok) {
+                        const bf16x4 mk = *(const bf16x4*)mp;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col + e < p.N) v[e] = (float)mp[e] > 0.f ? v[e] : 0.f;
+                    }
+                }
+                if (p.drop) {
+                    const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
+                }
+                if (p.residual) {
+                    const float* rp = p.residual + (int64_t)row * p.ldr + col;
+                    if (full) v += *(const f32x4*)rp;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col + e < p.N) v[e] += rp[e];
+                    }
+                }
+                TO* cp = Cp + (int64_t)row * p.ldc + col;
+                if (full) {
+                    if (sizeof(TO) == 4) *(f32x4*)cp = v;
+                    else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+                        *(bf16x4*)cp = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (col + e < p.N) cp[e] = from_f32<TO>(v[e]);
+                }
+            }
+        }
+    };
+    u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
+    __builtin_amdgcn_s_barrier();                                  // stage 0 published by the loaders
+    read_frags(fa0, fb0, 0);
+    int kt = 0, tile_i = 0;
+    for (int g = 0; g < total; g += 2) {                           // total is even (K % 64 == 0)
+        __builtin_amdgcn_s_barrier();                              // stage g+1 visible
+        read_frags(fa1, fb1, g + 1);
+        mma_all(fa0, fb0);
+        if (g + 2 < total) {
+            __builtin_amdgcn_s_barrier();                          // stage g+2 visible
+            read_frags(fa0, fb0, g + 2);
+        }
+        mma_all(fa1, fb1);
+        kt += 2;
+        if (kt == nk) { epilogue(tile_i); kt = 0; ++tile_i; }
+    }
+}
+
 static unsigned long long* g_stamp_buffer = nullptr;
 // diagnostic only (tools/gemm_stamps.py): not part of the public header
 extern "C" void dg_debug_set_stamp_buffer(void* p) { g_stamp_buffer = (unsigned long long*)p; }
 
 // bf16 NT variant switch for A/B benchmarking: DG_GEMM_NT = 0 wave-specialised persistent LDS-DMA (default),
-// 1 register-staged, 2 LDS-DMA one tile per workgroup, 4 persistent LDS-DMA without loader waves
+// 1 register-staged, 2 LDS-DMA one tile per workgroup, 4 persistent LDS-DMA without loader waves, 5 the 256 x 128 experiment
 static int dg_nt_mode() {
     static const int v = [] { const char* e = getenv("DG_GEMM_NT"); return e ? atoi(e) : 0; }();
     return v;
@@ -783,6 +976,11 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
         dim3 pgrid(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
         if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_pers_kernel<bf16_t>), pgrid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_nt_pers_kernel<float>), pgrid, dim3(512), 0, s, p);
+    } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 5) {
+        const int n2 = ((a->M + 255) / 256) * p.tiles_n;
+        dim3 pgrid(n2 < dg_num_cus() ? n2 : dg_num_cus());
+        if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws2_kernel<bf16_t>), pgrid, dim3(768), 0, s, p);
+        else hipLaunchKernelGGL((gemm_nt_ws2_kernel<float>), pgrid, dim3(768), 0, s, p);
     } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 0) {
         dim3 pgrid(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
         if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t>), pgrid, dim3(512 + 64 * WS_NLOAD), 0, s, p);
