@@ -424,16 +424,30 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     auto epilogue = [&](int ti) -> bool {
         const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
         const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-        const bool interior = p.vec_ok && (m0 + BM <= p.M) && (n0 + BN <= p.N) && p.dbg == 0;
-        const int ch = lane & 15;                              // 16-byte chunk = 4 columns
-        const int col = n0 + wn * 64 + ch * 4;
-        const bool full = p.vec_ok && (col + 3 < p.N);
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && col < p.N) {
-            if (full) bv = *(const f32x4*)(p.bias + col);
-            else {
+        const bool vok = p.vec_ok && (sizeof(TO) == 4 || (((p.ldc & 7) == 0) && (((uintptr_t)Cp & 15) == 0)));
+        const bool interior = vok && (m0 + BM <= p.M) && (n0 + BN <= p.N) && p.dbg == 0;
+        // The store path retires about one lane address per cycle whatever the lane's width, so every
+        // lane stores 16 bytes: 4 columns of an fp32 output, 8 columns of a bf16 one.
+        constexpr int CPL = sizeof(TO) == 4 ? 4 : 8;           // columns per lane
+        constexpr int LPR = 64 / CPL;                          // lanes per 64-column row
+        constexpr int RPI = 64 / LPR;                          // rows per iteration
+        const int ch = lane & (LPR - 1);
+        const int col = n0 + wn * 64 + ch * CPL;
+        const bool full = vok && (col + CPL - 1 < p.N);
+        float bv[CPL];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
+        for (int e = 0; e < CPL; ++e) bv[e] = 0.f;
+        if (p.bias && col < p.N) {
+            if (full) {
+#pragma unroll
+                for (int q = 0; q < CPL / 4; ++q) {
+                    const f32x4 t = *(const f32x4*)(p.bias + col + q * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[q * 4 + e] = t[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
             }
         }
 #pragma unroll
@@ -445,55 +459,72 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int lrow = it * 4 + (lane >> 4);
+            for (int it = 0; it < 16 / RPI; ++it) {
+                const int lrow = it * RPI + lane / LPR;
                 const int row = m0 + wm * 32 + i * 16 + lrow;
-                f32x4 v = *(const f32x4*)(stage + lrow * 64 + ((ch ^ lrow) << 2));
+                float v[CPL];
+#pragma unroll
+                for (int q = 0; q < CPL / 4; ++q) {
+                    const f32x4 t = *(const f32x4*)(stage + lrow * 64 + (((ch * (CPL / 4) + q) ^ lrow) << 2));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[q * 4 + e] = t[e];
+                }
                 if (row >= p.M || col >= p.N) continue;
                 if (p.dbg >= 3 && v[0] != 12345.678f) continue;      // ablation: no stores
-                v += bv;
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) v[e] += bv[e];
                 if (p.relu) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < CPL; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
                 if (p.relu_mask) {
                     const bf16_t* mp = (const bf16_t*)p.relu_mask + (int64_t)row * p.ldmask + col;
                     if (full && p.mask_vec_ok) {
-                        const bf16x4 mk = *(const bf16x4*)mp;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
+                        for (int q = 0; q < CPL / 4; ++q) {
+                            const bf16x4 mk = *(const bf16x4*)(mp + q * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[q * 4 + e] = (float)mk[e] > 0.f ? v[q * 4 + e] : 0.f;
+                        }
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                        for (int e = 0; e < CPL; ++e)
                             if (col + e < p.N) v[e] = (float)mp[e] > 0.f ? v[e] : 0.f;
                     }
                 }
                 if (p.drop) {
                     const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
+                    for (int e = 0; e < CPL; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
                 }
                 if (p.residual) {
                     const float* rp = p.residual + (int64_t)row * p.ldr + col;
-                    if (full) v += *(const f32x4*)rp;
-                    else {
+                    if (full) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                        for (int q = 0; q < CPL / 4; ++q) {
+                            const f32x4 t = *(const f32x4*)(rp + q * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[q * 4 + e] += t[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < CPL; ++e)
                             if (col + e < p.N) v[e] += rp[e];
                     }
                 }
                 TO* cp = Cp + (int64_t)row * p.ldc + col;
                 if (full) {
-                    if (sizeof(TO) == 4) *(f32x4*)cp = v;
-                    else {
-                        bf16x4 o;
+                    if constexpr (sizeof(TO) == 4) {
+                        *(f32x4*)cp = (f32x4){v[0], v[1], v[2], v[3]};
+                    } else {
+                        bf16x8 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-                        *(bf16x4*)cp = o;
+                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                        *(bf16x8*)cp = o;
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < CPL; ++e)
                         if (col + e < p.N) cp[e] = from_f32<TO>(v[e]);
                 }
             }
