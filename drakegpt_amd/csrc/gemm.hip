@@ -367,6 +367,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     auto issue = [&](int g) {
         char* base = lds + (g & (GL_NST - 1)) * GL_STAGE + (WS_PPL * lw) * 1024;
         const int64_t koff = (int64_t)iss_kt * 128;
+        if (!((p.dbg == 1 || p.dbg == 4) && g > 0))             // ablation: no operand traffic after the first stage
 #pragma unroll
         for (int i = 0; i < WS_PPL; ++i) {
             __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + i * 1024), 16, 0, 0);
@@ -555,6 +556,238 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
         if (p.dbg != 2) mma_all(fa1, fb1);
         stamp();
         if (++kt == nk) { epilogue(tile_i); kt = 0; ++tile_i; stamp(); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Paired-workgroup EXPERIMENT (DG_GEMM_NT=6; measured 20-35% SLOWER than gemm_nt_ws_kernel on every shape of the
+// step, so not the default -- kept for the register-only epilogue): TWO 384-thread workgroups share a CU (80 KB of LDS and 6 waves
+// each: 4 MFMA waves in 2x2 with 64x64 wave tiles + 2 loader waves), so while one workgroup sits in
+// its epilogue, its first-stage latency or a barrier, the other one keeps the MFMA pipes busy -- the
+// one-workgroup-per-CU kernels above spend ~45% of a K = 384 tile in the epilogue with the matrix
+// cores idle (measured: tools/gemm_stamps.py, DG_GEMM_DBG ablations).  Differences from gemm_nt_ws_kernel:
+//   * K step of 32 (stage = 2 x [128 rows][64 B] = 16 KB), five stages in a ring; a stage is issued
+//     three barriers before it is read;
+//   * 64x64 wave tiles: 8 fragment reads per 16 MFMAs (the 32x64 tiles needed 12);
+//   * no LDS staging in the epilogue: v_permlane16_swap exchanges accumulator quads between lane
+//     rows so that every lane owns 8 consecutive output columns and stores 16 B (bf16) / 2 x 16 B (fp32).
+#define PP_BK 32
+#define PP_NS 5
+#define PP_STAGE 16384
+// [128 rows][64 B] operand image: 16-byte slot XORed with (row>>2)&3 -- conflict-free for the
+// fragment reads (16 rows x one k-chunk per quarter wave) and realised on the LDS-DMA source side.
+__device__ __forceinline__ int pp_lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <typename TO>
+__global__ __launch_bounds__(384, 2) void gemm_nt_pp_kernel(NtParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[PP_NS * PP_STAGE];      // 80 KB: two workgroups fill the CU's 160 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x;
+    const int my_tiles = (p.n_tiles - (int)blockIdx.x + G - 1) / G;
+    const int nk = p.K / PP_BK;
+    const int total = my_tiles * nk;
+
+    if (wave >= 4) {
+        // ---- loader role: per stage 4 + 4 LDS-DMA pieces of 1 KB (16 rows x 64 B) per wave
+        const int lw = wave - 4;
+        const int prow = lane >> 2, slot = lane & 3;
+        const int chunk = slot ^ ((prow >> 2) & 3);
+        const char* srcA[4];
+        const char* srcB[4];
+        auto set_src = [&](int ti) {
+            const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
+            const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (lw * 4 + i) * 16 + prow;
+                int gm = m0 + row; if (gm > p.M - 1) gm = p.M - 1;
+                int gn = n0 + row; if (gn > p.N - 1) gn = p.N - 1;
+                srcA[i] = p.A + (int64_t)gm * p.lda_b + chunk * 16;
+                srcB[i] = p.B + (int64_t)gn * p.ldb_b + chunk * 16;
+            }
+        };
+        int iss_tile = 0, iss_kt = 0, iss_buf = 0;
+        auto issue = [&]() {
+            char* base = lds + iss_buf * PP_STAGE + (lw * 4) * 1024;
+            const int64_t koff = (int64_t)iss_kt * (PP_BK * 2);
+            if (!((p.dbg == 1 || p.dbg == 4) && (iss_tile | iss_kt)))     // ablation: no operand traffic after the first stage
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + i * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + koff), (lptr_t)(base + 8192 + i * 1024), 16, 0, 0);
+            }
+            if (++iss_buf == PP_NS) iss_buf = 0;
+            if (++iss_kt == nk) { iss_kt = 0; if (++iss_tile < my_tiles) set_src(iss_tile); }
+        };
+        auto wait_allow = [&](int stages_in_flight) {              // 8 LDS-DMA instructions per stage per wave
+            if (stages_in_flight >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (stages_in_flight == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (stages_in_flight == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        set_src(0);
+        const int npre = total < PP_NS - 1 ? total : PP_NS - 1;
+        for (int g = 0; g < npre; ++g) issue();
+        wait_allow(npre - 1);
+        __builtin_amdgcn_s_barrier();                              // stage 0 published
+        for (int b = 0; b + 1 < total; ++b) {
+            int issued = b + PP_NS - 1; if (issued > total) issued = total;
+            wait_allow(issued - (b + 2));                          // stage b+1 landed; b+2, b+3 may fly
+            __builtin_amdgcn_s_barrier();                          // publishes stage b+1; stage b-1's buffer is free
+            if (b + PP_NS - 1 < total) issue();                    // stage b+4 -> buffer of stage b-1
+        }
+        return;
+    }
+
+    // ---- MFMA role
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int offA = pp_lds_off(wm * 64 + fr, fg), offB = 8192 + pp_lds_off(wn * 64 + fr, fg);   // +i*16 rows keeps the swizzle term
+    auto read_frags = [&](u32x4 (&fa)[4], u32x4 (&fb)[4], const char* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *(const u32x4*)(buf + offA + i * 16 * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(buf + offB + j * 16 * 64);
+    };
+    auto mma_all = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[4]) {        // transposed: D rows = n, cols = m
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
+    };
+    uint32_t key = 0;
+    if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
+    TO* Cp = (TO*)p.C;
+    const bool vok = p.vec_ok && (((p.ldc * sizeof(TO)) & 15) == 0) && (((uintptr_t)Cp & 15) == 0);
+
+    // Epilogue straight from the accumulators.  acc[i][j] of lane (fr, fg) is row i*16+fr, columns j*16+fg*4..+3;
+    // swapping the odd 16-lane rows of acc[i][2q] with the even rows of acc[i][2q+1] leaves each lane with 8
+    // consecutive columns starting at (2q + (fg&1))*16 + (fg>>1)*8.
+    auto epilogue = [&](int ti) {
+        const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
+        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int col = n0 + wn * 64 + (2 * q + (fg & 1)) * 16 + (fg >> 1) * 8;
+            const bool full = vok && (col + 7 < p.N);
+            float bv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+            if (p.bias && col < p.N) {
+                if (full) {
+                    const f32x4 b0 = *(const f32x4*)(p.bias + col), b1 = *(const f32x4*)(p.bias + col + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + wm * 64 + i * 16 + fr;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][2 * q][e], y = acc[i][2 * q + 1][e];
+                    // (inline asm: the clang builtin folded the four per-element swaps of a quad into one)
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+                    v[e] = x;
+                    v[4 + e] = y;
+                }
+                acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (row >= p.M || col >= p.N) continue;
+                if (p.dbg >= 3 && v[0] != 12345.678f) continue;      // ablation: no stores
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (p.relu_mask) {
+                    const bf16_t* mp = (const bf16_t*)p.relu_mask + (int64_t)row * p.ldmask + col;
+                    if (full && p.mask_vec_ok) {
+                        const bf16x4 m0v = *(const bf16x4*)mp, m1v = *(const bf16x4*)(mp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = (float)m0v[e] > 0.f ? v[e] : 0.f;
+                            v[4 + e] = (float)m1v[e] > 0.f ? v[4 + e] : 0.f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (col + e < p.N) v[e] = (float)mp[e] > 0.f ? v[e] : 0.f;
+                    }
+                }
+                if (p.drop) {
+                    const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
+                }
+                if (p.residual) {
+                    const float* rp = p.residual + (int64_t)row * p.ldr + col;
+                    if (full) {
+                        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (col + e < p.N) v[e] += rp[e];
+                    }
+                }
+                TO* cp = Cp + (int64_t)row * p.ldc + col;
+                if (full) {
+                    if constexpr (sizeof(TO) == 4) {
+                        *(f32x4*)cp = (f32x4){v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                    } else {
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                        *(bf16x8*)cp = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (col + e < p.N) cp[e] = from_f32<TO>(v[e]);
+                }
+            }
+        }
+    };
+
+    u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
+    __builtin_amdgcn_s_barrier();                                  // stage 0 published by the loaders
+    read_frags(fa0, fb0, lds);
+    int kt = 0, tile_i = 0, buf_i = 0;
+    // two K steps per trip so the fragment double buffer needs no register copies
+    for (int g = 0; g < total; g += 2) {
+        {
+            int nb = buf_i + 1; if (nb == PP_NS) nb = 0;
+            if (g + 1 < total) {
+                __builtin_amdgcn_s_barrier();                      // stage g+1 visible (stage g-1's buffer goes back to the loaders)
+                read_frags(fa1, fb1, lds + nb * PP_STAGE);
+            }
+            mma_all(fa0, fb0);
+            buf_i = nb;
+            if (++kt == nk) { epilogue(tile_i); kt = 0; ++tile_i; }
+        }
+        if (g + 1 < total) {
+            int nb = buf_i + 1; if (nb == PP_NS) nb = 0;
+            if (g + 2 < total) {
+                __builtin_amdgcn_s_barrier();
+                read_frags(fa0, fb0, lds + nb * PP_STAGE);
+            }
+            mma_all(fa1, fb1);
+            buf_i = nb;
+            if (++kt == nk) { epilogue(tile_i); kt = 0; ++tile_i; }
+        }
     }
 }
 
@@ -951,9 +1184,15 @@ __global__ __launch_bounds__(768) void gemm_nt_ws2_kernel(NtParams p) {
 static unsigned long long* g_stamp_buffer = nullptr;
 // diagnostic only (tools/gemm_stamps.py): not part of the public header
 extern "C" void dg_debug_set_stamp_buffer(void* p) { g_stamp_buffer = (unsigned long long*)p; }
+extern "C" int dg_debug_pp_occupancy() {      // workgroups of the paired kernel the runtime will co-schedule on one CU
+    int n = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_nt_pp_kernel<bf16_t>, 384, 0) != hipSuccess) return -1;
+    return n;
+}
 
 // bf16 NT variant switch for A/B benchmarking: DG_GEMM_NT = 0 wave-specialised persistent LDS-DMA (default),
-// 1 register-staged, 2 LDS-DMA one tile per workgroup, 4 persistent LDS-DMA without loader waves, 5 the 256 x 128 experiment
+// 1 register-staged, 2 LDS-DMA one tile per workgroup, 4 persistent LDS-DMA without loader waves, 5 the 256 x 128 experiment,
+// 6 the paired-workgroup experiment
 static int dg_nt_mode() {
     static const int v = [] { const char* e = getenv("DG_GEMM_NT"); return e ? atoi(e) : 0; }();
     return v;
@@ -1012,6 +1251,11 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
         dim3 pgrid(n2 < dg_num_cus() ? n2 : dg_num_cus());
         if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws2_kernel<bf16_t>), pgrid, dim3(768), 0, s, p);
         else hipLaunchKernelGGL((gemm_nt_ws2_kernel<float>), pgrid, dim3(768), 0, s, p);
+    } else if (a->in_dtype == DG_BF16 && a->K % 32 == 0 && a->K >= 64 && dg_nt_mode() == 6) {
+        const int slots = 2 * dg_num_cus();
+        dim3 pgrid(p.n_tiles < slots ? p.n_tiles : slots);
+        if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_pp_kernel<bf16_t>), pgrid, dim3(384), 0, s, p);
+        else hipLaunchKernelGGL((gemm_nt_pp_kernel<float>), pgrid, dim3(384), 0, s, p);
     } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 0) {
         dim3 pgrid(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
         if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t>), pgrid, dim3(512 + 64 * WS_NLOAD), 0, s, p);

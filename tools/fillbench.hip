@@ -1,0 +1,250 @@
+// Micro-benchmark of the global -> LDS fill path on gfx950 (what bounds the GEMM K step).
+//   hipcc -O3 --offload-arch=gfx950 tools/fillbench.hip -o tools/bin/fillbench && tools/bin/fillbench
+// Each workgroup streams 32 KB "stages" (256 rows x 128 B, the GEMM's A+B stage) from an L2-resident
+// region into LDS and reports cycles per stage, for: LDS-DMA (global_load_lds b128), register loads
+// + ds_write, with 1..12 issuing waves, and with 8 / 32 / 64 / 256 workgroups (1 / 4 / 8 / 32 CUs per XCD).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// mode 0: LDS-DMA, mode 1: global_load_dwordx4 + ds_write_b128
+template <int MODE>
+__global__ __launch_bounds__(768) void fill_kernel(const char* src, size_t region, int row_stride, int iters, int nload, int nreg, long long* out, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const char* base = src + (size_t)((blockIdx.x >> 3) % nreg) * region;   // workgroups b, b+8, .. share an XCD (and its L2)
+    // one stage = 32 pieces of 1 KB (8 rows x 128 B); wave w takes pieces w, w+nload, ...
+    const int prow = lane >> 3, slot = lane & 7;
+    long long t0 = 0;
+    float acc = 0.f;
+    if (wave < nload) {
+        const int ppl = 32 / nload;
+        t0 = __builtin_amdgcn_s_memtime();
+        for (int it = 0; it < iters; ++it) {
+            const char* sb = base + (size_t)(it % 6) * 128;             // K offset inside a 768 B row segment
+            char* db = lds + (it & 3) * 32768;
+#pragma unroll 8
+            for (int i = 0; i < ppl; ++i) {
+                const int piece = wave * ppl + i;
+                const char* g = sb + (size_t)(piece * 8 + prow) * row_stride + slot * 16;
+                if (MODE == 0) {
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(db + piece * 1024), 16, 0, 0);
+                } else {
+                    const u32x4 v = *(const u32x4*)g;
+                    *(u32x4*)(db + piece * 1024 + lane * 16) = v;
+                }
+            }
+            if (MODE == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long t1 = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && wave == 0) out[blockIdx.x] = t1 - t0;
+    }
+    __syncthreads();
+    acc += ((float*)lds)[tid];
+    if (acc == 123.456f) sink[0] = acc;
+}
+
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// GEMM K-step mock-up: waves 0..7 read MFMA fragments for a WM x WN wave tile from a 32 KB stage and run the MFMAs
+// (no barriers); waves 8..11 optionally stream L2-resident stages into LDS at full speed.  Reports cycles per K step.
+template <int WM, int WN>      // wave tile in units of 16 rows: 2x4 = the GEMM's 32x64, 4x4 = 64x64
+__global__ __launch_bounds__(768) void step_kernel(const char* src, size_t region, int row_stride, int iters, int with_dma, int with_mma,
+                                                  int nreg, long long* out, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const char* base = src + (size_t)((blockIdx.x >> 3) % nreg) * region;
+    const int prow = lane >> 3, slot = lane & 7;
+    if (wave >= 8) {
+        if (!with_dma) return;
+        const int lw = wave - 8;
+        if (with_dma >= 2) {                                  // GEMM-like: one barrier per K step shared with the consumers
+            for (int it = 0; it < iters; ++it) {
+                if (with_dma == 2) {
+                    const char* sb = base + (size_t)(it % 6) * 128;
+                    char* db = lds + ((it + 3) & 3) * 32768;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int piece = lw * 8 + i;
+                        __builtin_amdgcn_global_load_lds((gptr_t)(sb + (size_t)(piece * 8 + prow) * row_stride + slot * 16), (lptr_t)(db + piece * 1024), 16, 0, 0);
+                    }
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+        for (int it = 0; it < iters; ++it) {
+            const char* sb = base + (size_t)(it % 6) * 128;
+            char* db = lds + (it & 3) * 32768;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int piece = lw * 8 + i;
+                __builtin_amdgcn_global_load_lds((gptr_t)(sb + (size_t)(piece * 8 + prow) * row_stride + slot * 16), (lptr_t)(db + piece * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    const int fr = lane & 15, fg = lane >> 4;
+    constexpr int NWN = 128 / (WN * 16);                      // waves along n
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int rm = (wm * WM * 16) & 127, rn = (wn * WN * 16) & 127;
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    if (with_dma >= 2) {                                      // software-pipelined, barrier between the two MFMA batches
+        u32x4 fa0[WM], fb0[WN], fa1[WM], fb1[WN];
+        auto rd = [&](u32x4 (&fa)[WM], u32x4 (&fb)[WN], const char* buf, int ks) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) fa[i] = *(const u32x4*)(buf + lds_off(rm + i * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int j = 0; j < WN; ++j) fb[j] = *(const u32x4*)(buf + 16384 + lds_off(rn + j * 16 + fr, ks * 4 + fg));
+        };
+        auto mm = [&](const u32x4 (&fa)[WM], const u32x4 (&fb)[WN]) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+        };
+        rd(fa0, fb0, lds, 0);
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        for (int it = 0; it < iters; ++it) {
+            rd(fa1, fb1, lds + (it & 3) * 32768, 1);
+            mm(fa0, fb0);
+            __builtin_amdgcn_s_barrier();
+            rd(fa0, fb0, lds + ((it + 1) & 3) * 32768, 0);
+            mm(fa1, fb1);
+        }
+        const long long t1 = __builtin_amdgcn_s_memtime();
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) a += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (a == 123.456f) sink[0] = a;
+        if (lane == 0 && wave == 0) out[blockIdx.x] = t1 - t0;
+        return;
+    }
+    for (int it = 0; it < iters; ++it) {
+        const char* buf = lds + (it & 3) * 32768;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 fa[WM], fb[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) fa[i] = *(const u32x4*)(buf + lds_off(rm + i * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int j = 0; j < WN; ++j) fb[j] = *(const u32x4*)(buf + 16384 + lds_off(rn + j * 16 + fr, ks * 4 + fg));
+            if (with_mma) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) acc[i][0] += __builtin_bit_cast(f32x4, fa[i]);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[0][j] += __builtin_bit_cast(f32x4, fb[j]);
+            }
+        }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) a += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (a == 123.456f) sink[0] = a;
+    if (lane == 0 && wave == 0) out[blockIdx.x] = t1 - t0;
+}
+
+template <int WM, int WN>
+static void run_step(const char* name, int nwaves, const char* src, size_t region, int row_stride, int iters, long long* out, float* sink) {
+    CHECK(hipFuncSetAttribute((const void*)step_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    std::vector<long long> h(256);
+    for (int with_mma = 0; with_mma < 2; ++with_mma)
+        for (int with_dma = 0; with_dma < 4; ++with_dma) {
+            if (!with_mma && with_dma >= 2) continue;
+            hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+            float ms = 0.f;
+            const int big = iters * 20;                         // long enough for the clock to settle under load
+            for (int rep = 0; rep < 2; ++rep) {
+                CHECK(hipEventRecord(e0));
+                step_kernel<WM, WN><<<256, 768, 131072>>>(src, region, row_stride, big, with_dma, with_mma, 4, out, sink);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipDeviceSynchronize());
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+            }
+            CHECK(hipMemcpy(h.data(), out, 256 * sizeof(long long), hipMemcpyDeviceToHost));
+            double avg = 0; for (int i = 0; i < 256; ++i) avg += (double)h[i]; avg /= 256;
+            printf("step %s: mfma=%d dma=%d (0 none, 1 free-running, 2 dma + barrier per step, 3 barrier only): %7.1f cycles per K step of a 128x128x64 tile (consumer wave 0)\n", name, with_mma, with_dma, avg / big);
+            printf("      kernel %.1f us for %d steps -> %.1f ns per step -> s_memtime rate %.2f GHz; MFMA rate %.0f TFLOP/s\n", ms * 1e3, big, ms * 1e6 / big,
+                   avg / (ms * 1e6), with_mma ? 256.0 * 2 * 128 * 128 * 64 * big / (ms * 1e-3) / 1e12 : 0.0);
+        }
+}
+
+int main(int argc, char** argv) {
+    const int iters = 600;
+    const int row_stride = 768;                       // K = 384 bf16
+    const size_t region = 256 * (size_t)row_stride;   // 192 KB per workgroup: L2 resident
+    const int maxwg = 256;
+    char* src; long long* out; float* sink;
+    CHECK(hipMalloc(&src, region * maxwg + 4096));
+    CHECK(hipMemset(src, 1, region * maxwg + 4096));
+    if (argc > 2) {                                   // random bf16 payload (N(0,1)-like bit patterns): MFMA power depends on the data
+        std::vector<unsigned short> hb((region * maxwg) / 2);
+        unsigned x = 12345u;
+        for (auto& v : hb) { x = x * 1664525u + 1013904223u; const unsigned e = 120u + ((x >> 9) & 7u); v = (unsigned short)(((x >> 31) << 15) | (e << 7) | ((x >> 12) & 127u)); }
+        CHECK(hipMemcpy(src, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+        printf("payload: random bf16\n");
+    }
+    CHECK(hipMalloc(&out, maxwg * sizeof(long long)));
+    CHECK(hipMalloc(&sink, 16));
+    CHECK(hipFuncSetAttribute((const void*)fill_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CHECK(hipFuncSetAttribute((const void*)fill_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    std::vector<long long> h(maxwg);
+    run_step<2, 4>("8 waves of 32x64", 8, src, region, row_stride, iters, out, sink);
+    if (argc > 1) return 0;
+    for (int mode = 0; mode < 2; ++mode)
+      for (int nreg : {32, 4})
+        for (int nload : {2, 4, 8})
+            for (int wgs : {8, 64, 128, 256}) {
+                hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+                float ms = 0.f;
+                for (int rep = 0; rep < 2; ++rep) {
+                    CHECK(hipEventRecord(e0));
+                    if (mode == 0) fill_kernel<0><<<wgs, 768, 131072>>>(src, region, row_stride, iters, nload, nreg, out, sink);
+                    else fill_kernel<1><<<wgs, 768, 131072>>>(src, region, row_stride, iters, nload, nreg, out, sink);
+                    CHECK(hipEventRecord(e1));
+                    CHECK(hipDeviceSynchronize());
+                    CHECK(hipEventElapsedTime(&ms, e0, e1));
+                }
+                CHECK(hipMemcpy(h.data(), out, wgs * sizeof(long long), hipMemcpyDeviceToHost));
+                double avg = 0; for (int i = 0; i < wgs; ++i) avg += (double)h[i]; avg /= wgs;
+                // s_memtime ticks at 100 MHz; convert with the shader clock printed below
+                printf("mode=%s regions/xcd=%2d loaders=%d wgs=%3d : %7.1f ticks per 32KB stage (%.1f B/tick/CU), kernel %.1f us -> %.1f ns/stage, %.2f TB/s aggregate\n",
+                       mode == 0 ? "lds-dma" : "reg+dsw", nreg, nload, wgs, avg / iters, 32768.0 * iters / avg, ms * 1e3, ms * 1e6 / iters,
+                       32768.0 * iters * wgs / (ms * 1e-3) / 1e12);
+            }
+    int clk = 0; CHECK(hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0));
+    printf("hipDeviceAttributeClockRate %d kHz\n", clk);
+    return 0;
+}
