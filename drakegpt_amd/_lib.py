@@ -37,6 +37,16 @@ class GemmNtArgs(C.Structure):
     ]
 
 
+class TnProblem(C.Structure):
+    """struct dg_tn_problem"""
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64),
+        ("B", C.c_void_p), ("ldb", C.c_int64),
+        ("out", C.c_void_p), ("ldo", C.c_int64),
+        ("R", C.c_int32), ("P", C.c_int32), ("Q", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 
 # name -> argtypes; every entry of include/drakegpt_hip.h (tests/test_abi.py checks the two agree)
@@ -51,6 +61,7 @@ SIGNATURES = {
     "dg_layernorm_bwd_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _vp, _u32, _vp, _vp],
     "dg_gemm_nt": [C.POINTER(GemmNtArgs), _vp],
     "dg_gemm_tn": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp],
+    "dg_gemm_tn_grouped": [C.POINTER(TnProblem), _i, _i, _vp],
     "dg_reduce_partials": [_vp, _i64, _i, _vp, _i64, _vp],
     "dg_colsum": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _vp],
     "dg_dropout_bwd_cast": [_vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp, _u32, _vp, _i64, _vp, _i64, _i, _vp],

@@ -369,11 +369,46 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, int64_t s
     }
 }
 
+// Many partials of a short vector (the G = 256 row-chunk partials of the bias / LayerNorm gradients: n ~ 23 K):
+// one output per thread would leave ~6 K threads each walking 256 strided rows serially (110 us measured).  Here a
+// 1024-thread workgroup owns 64 float4 columns; 16 row groups each sum every 16th partial (independent loads in
+// flight) and are combined through LDS in a fixed order, so the result stays deterministic.
+__global__ __launch_bounds__(1024) void reduce_partials_tall_kernel(const float* __restrict__ part, int64_t stride, int n_partials,
+                                                                    float* __restrict__ out, int64_t n4) {
+    __shared__ f32x4 red[16][64];
+    const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + c;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (i < n4) {
+        int g = r;
+        for (; g + 16 < n_partials; g += 32) {
+            s0 += *(const f32x4*)(part + (int64_t)g * stride + i * 4);
+            s1 += *(const f32x4*)(part + (int64_t)(g + 16) * stride + i * 4);
+        }
+        if (g < n_partials) s0 += *(const f32x4*)(part + (int64_t)g * stride + i * 4);
+    }
+    red[r][c] = s0 + s1;
+    __syncthreads();
+    if (r == 0 && i < n4) {
+        f32x4 t = red[0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][c];
+        ((f32x4*)out)[i] = t;
+    }
+}
+
 extern "C" int dg_reduce_partials(const float* partials, int64_t stride, int n_partials,
                                   float* out, int64_t n, void* stream) {
     if (!partials || !out || n_partials <= 0 || n < 0) return DG_ERR_ARG;
     if (n == 0) return DG_OK;
     int vec_ok = dg_aligned16(partials) && dg_aligned16(out) && (stride % 4 == 0);
+    if (vec_ok && n_partials >= 32 && n % 4 == 0 && n / 4 < (int64_t)n_partials * 4096) {
+        const int64_t n4 = n / 4;
+        hipLaunchKernelGGL(reduce_partials_tall_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
+                           partials, stride, n_partials, out, n4);
+        DG_LAUNCH_CHECK();
+        return DG_OK;
+    }
     int64_t work = vec_ok ? (n + 3) / 4 : n;
     unsigned grid = (unsigned)((work + 255) / 256);
     if (grid > 4096) grid = 4096;

@@ -988,6 +988,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pers_kernel(NtParams p) {
     }
 }
 
+
 // ---------------------------------------------------------------------------------------------
 // EXPERIMENT (DG_GEMM_NT=5 only; not used by default): 256 x 128 tile, 32-deep K steps, six 24 KB stages --
 // 25 % fewer operand bytes per FLOP than the 128 x 128 kernel, same wave specialisation.  Measured on the
@@ -1617,6 +1618,163 @@ __global__ __launch_bounds__(768) void gemm_tn_ws_kernel(TnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Grouped dW GEMM: every weight gradient of the step in one persistent launch.  Same stage format,
+// loader / MFMA wave split and fragment reads as gemm_tn_ws_kernel, but a workgroup walks its tiles
+// (of any problem of the group) with ONE continuous stage pipeline and each tile runs over the whole
+// contraction, so there are no split-K slabs to write, re-read and reduce (they were ~790 MB per step)
+// and no per-matrix launch: 651 tiles of 256 K steps instead of 25 launches of <= 256 short workgroups.
+#define TN_MAX_GROUP 32
+struct TnProblem {
+    const char* A; const char* B; float* out;
+    int64_t lda_b, ldb_b, ldo;
+    int P, Q, R, tiles_q, tile_begin, pad;
+};
+struct TnGroup { int n, total_tiles; TnProblem pr[TN_MAX_GROUP]; };
+
+__global__ __launch_bounds__(768) void gemm_tn_grouped_kernel(TnGroup gp) {
+    __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wq = wave & 1;
+    const int G = gridDim.x;
+    const int my_tiles = (gp.total_tiles - (int)blockIdx.x + G - 1) / G;
+    auto locate = [&](int ti, int& pi, int& p0, int& q0) {
+        const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, gp.total_tiles);
+        pi = 0;
+        for (int i = 1; i < gp.n; ++i)
+            if (tile >= gp.pr[i].tile_begin) pi = i;
+        const int local = tile - gp.pr[pi].tile_begin;
+        p0 = (local / gp.pr[pi].tiles_q) * 128; q0 = (local % gp.pr[pi].tiles_q) * 128;
+    };
+    int total = 0;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        int pi, p0, q0;
+        locate(ti, pi, p0, q0);
+        total += gp.pr[pi].R / 64;
+    }
+
+    if (wave >= 8) {
+        // ---- loader role: piece = 1 KB = 4 rows x 256 B; this wave moves pieces 4lw..4lw+3 of A and of B per stage
+        const int lw = wave - 8;
+        const int prow = lane >> 4, slot = lane & 15;
+        const char* srcA[4];
+        const char* srcB[4];
+        int64_t stepA = 0, stepB = 0;
+        int nk_iss = 1;
+        auto set_src = [&](int ti) {
+            int pi, p0, q0;
+            locate(ti, pi, p0, q0);
+            const TnProblem& pr = gp.pr[pi];
+            nk_iss = pr.R / 64;
+            stepA = 64 * pr.lda_b; stepB = 64 * pr.ldb_b;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = 4 * lw + i;
+                const int row = 4 * q + prow;
+                const int chunk = slot ^ ((prow << 2) | (q & 3));
+                int ca = p0 + chunk * 8; if (ca + 8 > pr.lda_b / 2) ca = 0;   // past the leading dimension: clamp
+                int cb = q0 + chunk * 8; if (cb + 8 > pr.ldb_b / 2) cb = 0;
+                srcA[i] = pr.A + (int64_t)row * pr.lda_b + (int64_t)ca * 2;
+                srcB[i] = pr.B + (int64_t)row * pr.ldb_b + (int64_t)cb * 2;
+            }
+        };
+        int iss_tile = 0, iss_kt = 0;
+        auto issue = [&](int g) {
+            char* base = lds + (g & (GL_NST - 1)) * GL_STAGE + (4 * lw) * 1024;
+            const int64_t ra = (int64_t)iss_kt * stepA, rb = (int64_t)iss_kt * stepB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + ra), (lptr_t)(base + i * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + rb), (lptr_t)(base + 16384 + i * 1024), 16, 0, 0);
+            }
+            if (++iss_kt == nk_iss) { iss_kt = 0; if (++iss_tile < my_tiles) set_src(iss_tile); }
+        };
+        if (total > 0) {
+            set_src(0);
+            const int npre = total < GL_NST - 1 ? total : GL_NST - 1;
+            for (int g = 0; g < npre; ++g) issue(g);
+            if (npre >= 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (npre == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int g = 0; g + 1 < total; ++g) {
+                int issued = g + GL_NST - 1; if (issued > total) issued = total;
+                if (issued - (g + 2) >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (g + GL_NST - 1 < total) issue(g + GL_NST - 1);
+            }
+        }
+        return;
+    }
+    if (total == 0) return;
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    auto read_frags = [&](u32x4 (&fa)[2], u32x4 (&fb)[4], const char* buf, int ks) {
+        const int r0 = ks * 32 + fg * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = tn_frag_bf16(buf, r0, wp * 32 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = tn_frag_bf16(buf + 16384, r0, wq * 64 + j * 16, lane);
+    };
+    auto mma_all = [&](const u32x4 (&fa)[2], const u32x4 (&fb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
+    };
+    int cur_pi, cur_p0, cur_q0;
+    locate(0, cur_pi, cur_p0, cur_q0);
+    int nk_cur = gp.pr[cur_pi].R / 64;
+    auto store_tile = [&]() {
+        const TnProblem& pr = gp.pr[cur_pi];
+        float* out = pr.out;
+        const bool vec = (pr.ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = cur_p0 + wp * 32 + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = cur_q0 + wq * 64 + j * 16 + 4 * fg;
+                if (row < pr.P) {
+                    float* op = out + (int64_t)row * pr.ldo + col;
+                    if (vec && col + 3 < pr.Q) *(f32x4*)op = acc[i][j];
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col + e < pr.Q) op[e] = acc[i][j][e];
+                    }
+                }
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    u32x4 fa0[2], fb0[4], fa1[2], fb1[4];
+    __builtin_amdgcn_s_barrier();                                  // stage 0 published by the loaders
+    read_frags(fa0, fb0, lds, 0);
+    int kt = 0, tile_i = 0;
+    for (int g = 0; g < total; ++g) {
+        const char* buf = lds + (g & (GL_NST - 1)) * GL_STAGE;
+        read_frags(fa1, fb1, buf, 1);
+        mma_all(fa0, fb0);
+        if (g + 1 < total) {
+            __builtin_amdgcn_s_barrier();
+            read_frags(fa0, fb0, lds + ((g + 1) & (GL_NST - 1)) * GL_STAGE, 0);
+        }
+        mma_all(fa1, fb1);
+        if (++kt == nk_cur) {
+            store_tile();
+            kt = 0;
+            if (++tile_i < my_tiles) { locate(tile_i, cur_pi, cur_p0, cur_q0); nk_cur = gp.pr[cur_pi].R / 64; }
+        }
+    }
+}
+
 // ---- f32: [32 r][128 cols] tiles with 144-float row pitch (pad 16 floats: rows r, r+1 of one
 //      ds_read_b32 half-wave land on different banks)
 #define TNF_PITCH 144
@@ -1738,5 +1896,39 @@ extern "C" int dg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
     else if (dtype == DG_BF16) hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, block, 0, s, p);
     else hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, block, 0, s, p);
     DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtype, void* stream) {
+    if (!problems || n <= 0) return DG_ERR_ARG;
+    if (dtype != DG_BF16) return DG_ERR_DTYPE;
+    for (int i = 0; i < n; ++i) {
+        const dg_tn_problem& q = problems[i];
+        if (!q.A || !q.B || !q.out || q.R <= 0 || q.P <= 0 || q.Q <= 0 || q.R % 64) return DG_ERR_ARG;
+        if (q.lda % 8 || q.ldb % 8 || !dg_aligned16(q.A) || !dg_aligned16(q.B)) return DG_ERR_ALIGN;
+        if (q.lda < q.P || q.ldb < q.Q || q.ldo < q.Q) return DG_ERR_ARG;
+        if (((q.P + 7) / 8) * 8 > q.lda || ((q.Q + 7) / 8) * 8 > q.ldb) return DG_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < n; base += TN_MAX_GROUP) {
+        TnGroup gp;
+        gp.n = n - base < TN_MAX_GROUP ? n - base : TN_MAX_GROUP;
+        int tiles = 0;
+        for (int i = 0; i < gp.n; ++i) {
+            const dg_tn_problem& q = problems[base + i];
+            TnProblem& t = gp.pr[i];
+            t.A = (const char*)q.A; t.B = (const char*)q.B; t.out = q.out;
+            t.lda_b = q.lda * 2; t.ldb_b = q.ldb * 2; t.ldo = q.ldo;
+            t.P = q.P; t.Q = q.Q; t.R = q.R;
+            t.tiles_q = (q.Q + 127) / 128;
+            t.tile_begin = tiles;
+            t.pad = 0;
+            tiles += ((q.P + 127) / 128) * t.tiles_q;
+        }
+        gp.total_tiles = tiles;
+        const int grid = tiles < dg_num_cus() ? tiles : dg_num_cus();
+        hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(grid), dim3(768), 0, s, gp);
+        DG_LAUNCH_CHECK();
+    }
     return DG_OK;
 }

@@ -70,6 +70,20 @@ class ShadowWeights:
 class FlatSink:
     def __init__(self, eng: "TrainEngine"):
         self.e = eng
+        self.deferred = []           # (dY, X, dW view, P, Q): operands stay referenced until the grouped launch
+
+    def defer(self, key, dy, x, P, Q) -> bool:
+        if not self.e.grouped_dw:
+            return False
+        off, shape = self.e.layA.entries[key]
+        assert shape == (P, Q), (key, shape, P, Q)
+        self.deferred.append((dy, x, self.e.gflat[self.e.offA + off:self.e.offA + off + P * Q], P, Q))
+        return True
+
+    def flush(self):
+        if self.deferred:
+            ops.gemm_tn_grouped(self.deferred)
+            self.deferred = []
 
     def matrix(self, key, P, Q):
         off, shape = self.e.layA.entries[key]
@@ -117,6 +131,9 @@ class TrainEngine:
             raise ValueError(f"embedding_dim must be a multiple of {g} for {self.act}")
         self.S = S.n_splits_for(self.M)
         self.G = S.n_partials_for(self.M)
+        # bf16: every dW of the step comes from ONE grouped GEMM at the end of backward, written straight into the
+        # flat gradient (no split-K slabs); fp32 parity mode keeps the per-matrix split-K path
+        self.grouped_dw = self.act == torch.bfloat16 and self.M % 64 == 0
         self._build_layout()
         self._alloc_and_adopt()
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay], dtype=torch.float32, device=self.dev)
@@ -183,7 +200,7 @@ class TrainEngine:
         self.gflat = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
         self.m_ = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
         self.v_ = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
-        self.slabs = torch.zeros((self.S, self.layA.size), dtype=torch.float32, device=dev)
+        self.slabs = None if self.grouped_dw else torch.zeros((self.S, self.layA.size), dtype=torch.float32, device=dev)
         self.vparts = torch.zeros((self.G, self.layB.size), dtype=torch.float32, device=dev)
         NH, H = self.NH, self.H
 
@@ -295,7 +312,10 @@ class TrainEngine:
                                 {"wqkv": f"{l}.wqkv", "wproj": f"{l}.wproj", "bproj": f"{l}.bproj", "ln_w": f"{l}.ln1w", "ln_b": f"{l}.ln1b"},
                                 g_in=g_next)
         ops.embed_bwd(x_idx, dh.view(B, T, self.C), self.grad_view("tok"), self.grad_view("pos")[:T])
-        ops.reduce_partials(self.slabs, self.layA.size, self.S, self.gflat[self.offA:], self.layA.size)
+        if self.grouped_dw:
+            sink.flush()
+        else:
+            ops.reduce_partials(self.slabs, self.layA.size, self.S, self.gflat[self.offA:], self.layA.size)
         ops.reduce_partials(self.vparts, self.layB.size, self.G, self.gflat[self.offB:], self.layB.size)
 
     def _prog_fwd_bwd(self):

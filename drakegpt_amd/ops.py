@@ -205,6 +205,22 @@ def gemm_tn(A: Tensor, Bm: Tensor, out_part: Tensor, split_stride: int, n_splits
                          A.shape[0], P, Q, dt_code(A.dtype), _stream()), "dg_gemm_tn")
 
 
+def gemm_tn_grouped(problems) -> None:
+    """every dW of a backward pass in one launch: problems = [(A [R,>=P], B [R,>=Q], out [P,Q] fp32, P, Q), ...];
+    out_i = A_i[:, :P]^T B_i[:, :Q] over all R rows (bf16 operands, R % 64 == 0).  The caller keeps the operands alive."""
+    from ._lib import TnProblem
+    arr = (TnProblem * len(problems))()
+    for t, (A, Bm, out, P, Q) in zip(arr, problems):
+        _chk(A, "A", torch.bfloat16, contiguous=False)
+        _chk(Bm, "B", torch.bfloat16, contiguous=False)
+        _chk(out, "out", torch.float32, contiguous=False)
+        if A.shape[0] != Bm.shape[0] or out.numel() < P * Q:
+            raise RuntimeError("gemm_tn_grouped: operand mismatch")
+        t.A, t.lda, t.B, t.ldb, t.out, t.ldo = _p(A), _ld(A), _p(Bm), _ld(Bm), _p(out), Q
+        t.R, t.P, t.Q, t.reserved = A.shape[0], P, Q, 0
+    check(lib.dg_gemm_tn_grouped(arr, len(problems), dt_code(torch.bfloat16), _stream()), "dg_gemm_tn_grouped")
+
+
 def reduce_partials(part: Tensor, stride: int, n_partials: int, out: Tensor, n: int) -> None:
     _chk(part, "partials", torch.float32, contiguous=False)
     _chk(out, "out", torch.float32, contiguous=False)

@@ -124,6 +124,16 @@ class LocalSink:
         return out
 
 
+def weight_grad(sink, key: str, dy: Tensor, x: Tensor, P: int, Q: int) -> None:
+    """dW[P,Q] = dy[:, :P]^T x[:, :Q].  A sink with `defer` (engine, bf16) only records the operands and computes
+    every dW of the step in one grouped launch at the end of backward; otherwise split-K partials now."""
+    defer = getattr(sink, "defer", None)
+    if defer is not None and defer(key, dy, x, P, Q):
+        return
+    part, stride, n = sink.matrix(key, P, Q)
+    ops.gemm_tn(dy, x, part, stride, n, P, Q)
+
+
 @dataclass
 class Run:
     """per-call runtime configuration"""
@@ -187,14 +197,12 @@ def attn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], wqkv: Tensor, 
             part, stride, n = sink.vector(keys["bproj"], wproj.shape[0])
             g = ops.dropout_bwd_cast(dy, run.act, run.p(p_proj), run.rng, site_proj(layer), colsum_part=part,
                                      part_stride=stride, n_partials=n)
-        part, stride, n = sink.matrix(keys["wproj"], wproj.shape[0], wproj.shape[1])
-        ops.gemm_tn(g, o, part, stride, n, wproj.shape[0], wproj.shape[1])
+        weight_grad(sink, keys["wproj"], g, o, wproj.shape[0], wproj.shape[1])
         do = ops.gemm_nt(g, run.weights.bwd(wproj), run.act, K=wproj.shape[0])
     else:
         do = _as_act(run, dy)
     dqkv = ops.attn_bwd(qkv, o, do, lse, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer))
-    part, stride, n = sink.matrix(keys["wqkv"], wqkv.shape[0], wqkv.shape[1])
-    ops.gemm_tn(dqkv, h, part, stride, n, wqkv.shape[0], wqkv.shape[1])
+    weight_grad(sink, keys["wqkv"], dqkv, h, wqkv.shape[0], wqkv.shape[1])
     if not need_dx:
         return None
     if ln_w is not None:
@@ -237,13 +245,11 @@ def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2:
             part, stride, n = sink.vector(keys["b2"], w2.shape[0])
             g = ops.dropout_bwd_cast(dy, run.act, run.p(p), run.rng, site_ffn(layer), colsum_part=part, part_stride=stride,
                                      n_partials=n)
-        part, stride, n = sink.matrix(keys["w2"], w2.shape[0], w2.shape[1])
-        ops.gemm_tn(g, f, part, stride, n, w2.shape[0], w2.shape[1])
+        weight_grad(sink, keys["w2"], g, f, w2.shape[0], w2.shape[1])
         df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], relu_mask=f)
         part, stride, n = sink.vector(keys["b1"], w1.shape[0])
         ops.colsum(df, part, stride, n)
-    part, stride, n = sink.matrix(keys["w1"], w1.shape[0], w1.shape[1])
-    ops.gemm_tn(df, h, part, stride, n, w1.shape[0], w1.shape[1])
+    weight_grad(sink, keys["w1"], df, h, w1.shape[0], w1.shape[1])
     if not need_dx:
         return None
     if ln_w is not None:
@@ -270,8 +276,7 @@ def linear_bwd_from_act(run: Run, saved, g: Tensor, w: Tensor, has_bias: bool, s
     if has_bias and not bias_done:
         part, stride, n = sink.vector(keys["b"], N)
         ops.colsum(g, part, stride, n, N=N)
-    part, stride, n = sink.matrix(keys["w"], N, K)
-    ops.gemm_tn(g, xa, part, stride, n, N, K)
+    weight_grad(sink, keys["w"], g, xa, N, K)
     if not need_dx:
         return None
     return ops.gemm_nt(g, run.weights.bwd(w), torch.float32, K=pad_to(N, granule(run.act)))

@@ -130,6 +130,20 @@ int dg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb,
                float* out, int64_t ldo, int64_t split_stride, int n_splits,
                int R, int P, int Q, int dtype, void* stream);
 
+/* Grouped form of dg_gemm_tn: n independent weight-gradient problems in ONE launch, each over its whole
+ * contraction (no split, no partial slabs, no reduction pass): out_i[P_i,Q_i] = sum_r A_i[r,P_i] * B_i[r,Q_i].
+ * The 128x128 output tiles of all problems are dealt to persistent workgroups, so the step's ~25 small dW
+ * GEMMs (ref: autograd of every nn.Linear, src/model_component.py:321-323,392-393,454, src/model.py:599) fill
+ * the chip together at the end of backward.  bf16 operands only; R_i must be a multiple of 64; alignment as
+ * for dg_gemm_tn.  The operands must stay alive until this call (the caller keeps dY of every Linear). */
+typedef struct dg_tn_problem {
+    const void* A; int64_t lda;     /* dY [R,P] */
+    const void* B; int64_t ldb;     /* X  [R,Q] */
+    float* out; int64_t ldo;        /* dW [P,Q] fp32, overwritten */
+    int R, P, Q, reserved;
+} dg_tn_problem;
+int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtype, void* stream);
+
 /* out[i] = sum_{g < n_partials} partials[g*stride + i], i < n.  Deterministic order. */
 int dg_reduce_partials(const float* partials, int64_t stride, int n_partials,
                        float* out, int64_t n, void* stream);

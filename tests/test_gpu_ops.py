@@ -91,6 +91,52 @@ def test_gemm_tn(dev, dtype, R, P, Q, S):
     assert rel(out, ref) < 3e-6, rel(out, ref)
 
 
+def test_gemm_tn_grouped(dev):
+    """one launch for many dW problems (different shapes and contraction lengths, ragged P/Q, column-sliced operands);
+    more tiles than CUs so workgroups walk several tiles of different problems with one stage pipeline."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(1024, 384, 384), (1024, 1152, 384), (1024, 384, 1536), (1024, 1536, 384), (1024, 80, 384), (64, 200, 72),
+              (2048, 1536, 768), (512, 128, 128), (192, 264, 520)] * 2
+    shapes += [(256, 2048, 2048)]                       # 256 tiles on its own
+    probs, refs, outs = [], [], []
+    for i, (R, P, Q) in enumerate(shapes):
+        lda = (P + 7) // 8 * 8 + (8 if i % 3 == 0 else 0)            # padded / sliced leading dimensions
+        ldb = (Q + 7) // 8 * 8
+        A = torch.zeros(R, lda, dtype=torch.bfloat16)
+        A[:, :P] = torch.randn(R, P, generator=g).to(torch.bfloat16)
+        B = torch.zeros(R, ldb, dtype=torch.bfloat16)
+        B[:, :Q] = torch.randn(R, Q, generator=g).to(torch.bfloat16)
+        refs.append(A[:, :P].double().T @ B[:, :Q].double())
+        out = torch.full((P * Q,), float("nan"), device=dev)
+        outs.append(out)
+        probs.append((A.to(dev)[:, :P] if lda != P else A.to(dev), B.to(dev)[:, :Q] if ldb != Q else B.to(dev), out, P, Q))
+    assert sum(((P + 127) // 128) * ((Q + 127) // 128) for _, P, Q in shapes) > 256
+    ops.gemm_tn_grouped(probs)
+    torch.cuda.synchronize()
+    for out, ref, (R, P, Q) in zip(outs, refs, shapes):
+        assert rel(out.view(P, Q), ref) < 3e-6, (R, P, Q, rel(out.view(P, Q), ref))
+    with pytest.raises(RuntimeError):                   # contraction length must be a multiple of 64
+        ops.gemm_tn_grouped([(torch.zeros(100, 64, dtype=torch.bfloat16, device=dev), torch.zeros(100, 64, dtype=torch.bfloat16, device=dev),
+                              torch.zeros(64 * 64, device=dev), 64, 64)])
+
+
+@pytest.mark.parametrize("G,n,stride", [(256, 23104, 23104), (256, 1000, 1024), (37, 4096, 4100), (32, 2050, 2052), (8, 77, 80), (300, 64, 64)])
+def test_reduce_partials(dev, G, n, stride):
+    """both kernels (one output per thread / the tall many-partials form), padded strides, run-to-run identical"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(G + n)
+    part = torch.randn(G, stride, generator=g)
+    ref = part[:, :n].double().sum(0)
+    pd = part.to(dev)
+    out = torch.full((n,), float("nan"), device=dev)
+    ops.reduce_partials(pd, stride, G, out, n)
+    assert rel(out, ref) < 2e-6, rel(out, ref)
+    out2 = torch.empty_like(out)
+    ops.reduce_partials(pd, stride, G, out2, n)
+    assert torch.equal(out, out2)
+
+
 def test_gemm_tn_asymmetric(dev):
     """exact integer data through the transposed LDS reads (bf16) -- every element must match."""
     ops = _ops()
