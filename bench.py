@@ -180,7 +180,7 @@ def kernel_roofline(eng, offsets, peak_tflops):
     from drakegpt_amd import ops
 
     calls = []            # (symbol, flops, closure)
-    real_nt, real_tn = ops.gemm_nt, ops.gemm_tn
+    real_nt, real_tn, real_tng = ops.gemm_nt, ops.gemm_tn, ops.gemm_tn_grouped
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
 
     def nt(A, Bm, out_dtype, **kw):
@@ -190,7 +190,8 @@ def kernel_roofline(eng, offsets, peak_tflops):
         r = real_nt(A, Bm, out_dtype, **kw)
         to = "bf16" if out_dtype == torch.bfloat16 else "float"
         if A.dtype == torch.bfloat16 and K % 64 == 0 and K >= 128:        # dispatch rule of dg_gemm_nt
-            sym = f"gemm_nt_ws_kernel<{to}>"
+            pf = out_dtype == torch.bfloat16 and kw.get("relu_mask") is not None and kw.get("residual") is None
+            sym = f"gemm_nt_ws_kernel<{to},{'true' if pf else 'false'}>"
         else:
             sym = f"gemm_nt_kernel<{'bf16' if A.dtype == torch.bfloat16 else 'float'},{to}>"
         kw2 = dict(kw)
@@ -207,14 +208,20 @@ def kernel_roofline(eng, offsets, peak_tflops):
             sym = "gemm_tn_f32_kernel"
         calls.append((sym, 2.0 * A.shape[0] * P * Q, lambda: real_tn(A, Bm, out_part, split_stride, n_splits, P, Q, ldo)))
 
+    def tng(problems):
+        problems = list(problems)
+        real_tng(problems)
+        fl = sum(2.0 * A.shape[0] * P * Q for A, _, _, P, Q in problems)
+        calls.append(("gemm_tn_grouped_kernel", fl, lambda: real_tng(problems)))
+
     eng.set_offsets(offsets)
-    ops.gemm_nt, ops.gemm_tn = nt, tn
+    ops.gemm_nt, ops.gemm_tn, ops.gemm_tn_grouped = nt, tn, tng
     try:
         eng._prog_fwd_bwd()
         eng._prog_update()
         torch.cuda.synchronize()
     finally:
-        ops.gemm_nt, ops.gemm_tn = real_nt, real_tn
+        ops.gemm_nt, ops.gemm_tn, ops.gemm_tn_grouped = real_nt, real_tn, real_tng
     reps = 10
     agg = {}
     for sym, fl, fn in calls:

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(512) void gemm_nt_glds_kernel(NtParams p) {
 // serialise (they dominated at K = 384: six K steps per tile).  The accumulators are kept
 // TRANSPOSED (mfma(B, A)): a lane then owns 4 consecutive output columns of one row, so the
 // epilogue stores 8/16-byte pieces straight from registers and needs no LDS staging at all.
-template <typename TO>
+template <typename TO, bool PF>
 __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE + 8 * 4096];   // 4 stages + a 4 KB epilogue slice per wave = 160 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -417,99 +417,113 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     uint32_t key = 0;
     if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
     TO* Cp = (TO*)p.C;
-    // Epilogue: the transposed accumulators (lane = row fr, 4 consecutive columns per (i,j)) are
-    // passed through a wave-private 16 x 64 fp32 LDS slice (XOR-swizzled 16-byte chunks) and read
-    // back by rows, so one store instruction covers 4 whole rows (4-8 full cache lines) instead of
-    // 16 partial ones -- the stores were transaction-bound, not byte-bound.
-    float* stage = (float*)(lds + GL_NST * GL_STAGE + wave * 4096);
+    const bool vok = p.vec_ok && (((p.ldc * sizeof(TO)) & 15) == 0) && (((uintptr_t)Cp & 15) == 0);
+    // PF variant (bf16 output with a ReLU mask: dX of FFN2): the mask and bias of an interior tile are fetched into
+    // registers PF_AHEAD K steps before the tile ends.  Loaded inside the epilogue they cost a dependent HBM round
+    // trip per 16-row block with the matrix cores idle (55 us -> 42 us in the step).  Kept out of the other
+    // variants: the extra live registers slow their K loop by ~8% (measured).
+    constexpr int PF_AHEAD = 2;
+    bf16x8 pf_mask[2][2];
+    f32x4 pf_bias[2][2];
+    bool pf_ok = false;
+    auto prefetch_operands = [&](int ti) {
+        if constexpr (PF) {
+            const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
+            const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+            pf_ok = vok && (m0 + BM <= p.M) && (n0 + BN <= p.N);
+            if (!pf_ok) return;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int col = n0 + wn * 64 + (2 * q + (fg & 1)) * 16 + (fg >> 1) * 8;
+                if (p.bias) { pf_bias[q][0] = *(const f32x4*)(p.bias + col); pf_bias[q][1] = *(const f32x4*)(p.bias + col + 4); }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = m0 + wm * 32 + i * 16 + fr;
+                    pf_mask[q][i] = *(const bf16x8*)((const bf16_t*)p.relu_mask + (int64_t)row * p.ldmask + col);
+                }
+            }
+        }
+    };
+    // Epilogue straight from the accumulators.  acc[i][j] of lane (fr, fg) is row i*16+fr, columns j*16+fg*4..+3;
+    // swapping the odd 16-lane rows of acc[i][2q] with the even rows of acc[i][2q+1] leaves each lane with 8
+    // consecutive columns starting at (2q + (fg&1))*16 + (fg>>1)*8.
     auto epilogue = [&](int ti) -> bool {
         const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
         const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-        const bool vok = p.vec_ok && (sizeof(TO) == 4 || (((p.ldc & 7) == 0) && (((uintptr_t)Cp & 15) == 0)));
-        const bool interior = vok && (m0 + BM <= p.M) && (n0 + BN <= p.N) && p.dbg == 0;
-        // The store path retires about one lane address per cycle whatever the lane's width, so every
-        // lane stores 16 bytes: 4 columns of an fp32 output, 8 columns of a bf16 one.
-        constexpr int CPL = sizeof(TO) == 4 ? 4 : 8;           // columns per lane
-        constexpr int LPR = 64 / CPL;                          // lanes per 64-column row
-        constexpr int RPI = 64 / LPR;                          // rows per iteration
-        const int ch = lane & (LPR - 1);
-        const int col = n0 + wn * 64 + ch * CPL;
-        const bool full = vok && (col + CPL - 1 < p.N);
-        float bv[CPL];
 #pragma unroll
-        for (int e = 0; e < CPL; ++e) bv[e] = 0.f;
-        if (p.bias && col < p.N) {
-            if (full) {
+        for (int q = 0; q < 2; ++q) {
+            const int col = n0 + wn * 64 + (2 * q + (fg & 1)) * 16 + (fg >> 1) * 8;
+            const bool full = vok && (col + 7 < p.N);
+            float bv[8];
 #pragma unroll
-                for (int q = 0; q < CPL / 4; ++q) {
-                    const f32x4 t = *(const f32x4*)(p.bias + col + q * 4);
+            for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+            if (PF && p.bias && pf_ok) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[q * 4 + e] = t[e];
+                for (int e = 0; e < 4; ++e) { bv[e] = pf_bias[q][0][e]; bv[4 + e] = pf_bias[q][1][e]; }
+            } else if (p.bias && col < p.N) {
+                if (full) {
+                    const f32x4 b0 = *(const f32x4*)(p.bias + col), b1 = *(const f32x4*)(p.bias + col + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < CPL; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
             }
-        }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 2; ++i) {
+                const int row = m0 + wm * 32 + i * 16 + fr;
+                float v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *(f32x4*)(stage + fr * 64 + (((j * 4 + fg) ^ fr) << 2)) = acc[i][j];
-                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int it = 0; it < 16 / RPI; ++it) {
-                const int lrow = it * RPI + lane / LPR;
-                const int row = m0 + wm * 32 + i * 16 + lrow;
-                float v[CPL];
-#pragma unroll
-                for (int q = 0; q < CPL / 4; ++q) {
-                    const f32x4 t = *(const f32x4*)(stage + lrow * 64 + (((ch * (CPL / 4) + q) ^ lrow) << 2));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[q * 4 + e] = t[e];
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][2 * q][e], y = acc[i][2 * q + 1][e];
+                    // (inline asm: the clang builtin folded the four per-element swaps of a quad into one)
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+                    v[e] = x;
+                    v[4 + e] = y;
                 }
+                acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (row >= p.M || col >= p.N) continue;
                 if (p.dbg >= 3 && v[0] != 12345.678f) continue;      // ablation: no stores
 #pragma unroll
-                for (int e = 0; e < CPL; ++e) v[e] += bv[e];
+                for (int e = 0; e < 8; ++e) v[e] += bv[e];
                 if (p.relu) {
 #pragma unroll
-                    for (int e = 0; e < CPL; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
                 if (p.relu_mask) {
                     const bf16_t* mp = (const bf16_t*)p.relu_mask + (int64_t)row * p.ldmask + col;
-                    if (full && p.mask_vec_ok) {
+                    if (PF && pf_ok) {
 #pragma unroll
-                        for (int q = 0; q < CPL / 4; ++q) {
-                            const bf16x4 mk = *(const bf16x4*)(mp + q * 4);
+                        for (int e = 0; e < 8; ++e) v[e] = (float)pf_mask[q][i][e] > 0.f ? v[e] : 0.f;
+                    } else if (full && p.mask_vec_ok) {
+                        const bf16x4 m0v = *(const bf16x4*)mp, m1v = *(const bf16x4*)(mp + 4);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[q * 4 + e] = (float)mk[e] > 0.f ? v[q * 4 + e] : 0.f;
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = (float)m0v[e] > 0.f ? v[e] : 0.f;
+                            v[4 + e] = (float)m1v[e] > 0.f ? v[4 + e] : 0.f;
                         }
                     } else {
 #pragma unroll
-                        for (int e = 0; e < CPL; ++e)
+                        for (int e = 0; e < 8; ++e)
                             if (col + e < p.N) v[e] = (float)mp[e] > 0.f ? v[e] : 0.f;
                     }
                 }
                 if (p.drop) {
                     const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
 #pragma unroll
-                    for (int e = 0; e < CPL; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
+                    for (int e = 0; e < 8; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
                 }
                 if (p.residual) {
                     const float* rp = p.residual + (int64_t)row * p.ldr + col;
                     if (full) {
+                        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
 #pragma unroll
-                        for (int q = 0; q < CPL / 4; ++q) {
-                            const f32x4 t = *(const f32x4*)(rp + q * 4);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[q * 4 + e] += t[e];
-                        }
+                        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
                     } else {
 #pragma unroll
-                        for (int e = 0; e < CPL; ++e)
+                        for (int e = 0; e < 8; ++e)
                             if (col + e < p.N) v[e] += rp[e];
                     }
                 }
@@ -517,6 +531,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                 if (full) {
                     if constexpr (sizeof(TO) == 4) {
                         *(f32x4*)cp = (f32x4){v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
                     } else {
                         bf16x8 o;
 #pragma unroll
@@ -525,13 +540,12 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < CPL; ++e)
+                    for (int e = 0; e < 8; ++e)
                         if (col + e < p.N) cp[e] = from_f32<TO>(v[e]);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
         }
-        return interior;
+        return vok && (m0 + BM <= p.M) && (n0 + BN <= p.N);
     };
 
     int nstamp = 0;
@@ -546,8 +560,10 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     read_frags(fa0, fb0, lds, 0);
     stamp();
     int kt = 0, tile_i = 0;
+    const int pf_at = nk > PF_AHEAD ? nk - 1 - PF_AHEAD : 0;
     for (int g = 0; g < total; ++g) {
         const char* buf = lds + (g & (GL_NST - 1)) * GL_STAGE;
+        if (PF && kt == pf_at) prefetch_operands(tile_i);
         if (p.dbg != 2) { read_frags(fa1, fb1, buf, 1); mma_all(fa0, fb0); }
         if (g + 1 < total) {
             __builtin_amdgcn_s_barrier();                          // stage g+1 is visible; nothing to wait for here
@@ -1259,8 +1275,11 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
         else hipLaunchKernelGGL((gemm_nt_pp_kernel<float>), pgrid, dim3(384), 0, s, p);
     } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 0) {
         dim3 pgrid(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
-        if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t>), pgrid, dim3(512 + 64 * WS_NLOAD), 0, s, p);
-        else hipLaunchKernelGGL((gemm_nt_ws_kernel<float>), pgrid, dim3(512 + 64 * WS_NLOAD), 0, s, p);
+        const bool pf = a->out_dtype == DG_BF16 && a->relu_mask && !a->residual && p.vec_ok && p.mask_vec_ok && (a->ldmask % 8 == 0) &&
+                        dg_aligned16(a->relu_mask) && (a->ldc % 8 == 0) && dg_aligned16(a->C) && (!a->bias || dg_aligned16(a->bias));
+        if (pf) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true>), pgrid, dim3(512 + 64 * WS_NLOAD), 0, s, p);
+        else if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false>), pgrid, dim3(512 + 64 * WS_NLOAD), 0, s, p);
+        else hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false>), pgrid, dim3(512 + 64 * WS_NLOAD), 0, s, p);
     } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 2) {
         if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16_t>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_nt_glds_kernel<float>), grid, dim3(512), 0, s, p);

@@ -201,6 +201,31 @@ static void run_step(const char* name, int nwaves, const char* src, size_t regio
         }
 }
 
+
+// Store path: 8 waves write a [128 x 128] bf16 tile (32 KB) per iteration the way the GEMM epilogue does
+// (16 B per lane, 4 lanes... 8 lanes per 128-B row segment, rows ldc bytes apart), walking down a private output panel.
+__global__ __launch_bounds__(512) void store_kernel(char* dst, size_t panel_bytes, int ldc_bytes, int iters, int lanes_per_row, long long* out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    (void)panel_bytes;
+    const u32x4 v = {1u, 2u, 3u, 4u};
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        const int t = (int)blockIdx.x + it * (int)gridDim.x;        // tile (m-block t/9, n-block t%9) of a [M, 1152] bf16 matrix
+        char* tile = dst + (size_t)(t / 9) * 128 * ldc_bytes + (size_t)(t % 9) * 256;
+        // wave tile 32 rows x 64 cols (128 B per row): 4 KB = 4 instructions of 1 KB
+        for (int q = 0; q < 4; ++q) {
+            int row, colb;
+            if (lanes_per_row == 8) { row = wm * 32 + q * 8 + (lane >> 3); colb = wn * 128 + (lane & 7) * 16; }
+            else { row = wm * 32 + (q >> 1) * 16 + (lane & 15); colb = wn * 128 + (q & 1) * 64 + (lane >> 4) * 16; }   // 64-B runs (permlane form)
+            *(u32x4*)(tile + (size_t)row * ldc_bytes + colb) = v;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) out[blockIdx.x] = t1 - t0;
+}
+
 int main(int argc, char** argv) {
     const int iters = 600;
     const int row_stride = 768;                       // K = 384 bf16
@@ -221,6 +246,30 @@ int main(int argc, char** argv) {
     CHECK(hipFuncSetAttribute((const void*)fill_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CHECK(hipFuncSetAttribute((const void*)fill_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     std::vector<long long> h(maxwg);
+    {
+        const int iters_s = 1024, ldc_bytes = 2304;                // N = 1152 bf16
+        const size_t panel = 0;
+        char* dst; CHECK(hipMalloc(&dst, (size_t)((256 * (iters_s / 16) + 8) / 9 + 1) * 128 * ldc_bytes));
+        std::vector<long long> hs(256);
+        for (int lpr : {8, 4})
+            for (int wgs : {64, 256}) {
+                hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+                float ms = 0.f;
+                for (int rep = 0; rep < 2; ++rep) {
+                    CHECK(hipEventRecord(e0));
+                    store_kernel<<<wgs, 512>>>(dst, panel / 16, ldc_bytes, iters_s / 16, lpr, out);
+                    CHECK(hipEventRecord(e1));
+                    CHECK(hipDeviceSynchronize());
+                    CHECK(hipEventElapsedTime(&ms, e0, e1));
+                }
+                CHECK(hipMemcpy(hs.data(), out, wgs * sizeof(long long), hipMemcpyDeviceToHost));
+                double avg = 0; for (int i = 0; i < wgs; ++i) avg += (double)hs[i]; avg /= wgs;
+                const int it = iters_s / 16;
+                printf("store %s wgs=%3d : %7.1f cycles per 32 KB tile (%.1f B/cycle/CU); kernel %.1f us -> %.2f TB/s aggregate\n",
+                       lpr == 8 ? "128-B runs" : " 64-B runs", wgs, avg / it, 32768.0 * it / avg, ms * 1e3, 32768.0 * it * wgs / (ms * 1e-3) / 1e12);
+            }
+        CHECK(hipFree(dst));
+    }
     run_step<2, 4>("8 waves of 32x64", 8, src, region, row_stride, iters, out, sink);
     if (argc > 1) return 0;
     for (int mode = 0; mode < 2; ++mode)
