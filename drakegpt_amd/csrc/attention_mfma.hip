@@ -18,6 +18,7 @@
 // Scores per (b,h): T*(T+1)/2; FLOP per score element: fwd 4*64, bwd 10*64 (+2 recomputed products
 // because dQ and dK/dV are separate deterministic passes: no atomics, bitwise reproducible).
 #include "common.h"
+#include <stdlib.h>
 
 #define HD 64
 #define TILE 32
@@ -33,7 +34,32 @@ struct AttnP {
     int64_t n_items;
     float scale;
     int drop; float inv_keep; uint32_t thr; const uint32_t* rng; uint32_t site;
+    int balance, rot_div;      // balance: 0 plain, 1 = cost-balanced item order (nblk % 4 == 0); rot_div = #CUs
 };
+
+// Which 32-row block does this wave work on?  A causal block b costs b+1 tile iterations (nblk-b for the dK/dV
+// kernel), so "4 consecutive blocks per workgroup" gave workgroups of cost 26 and 10 at T = 256, and since a CU
+// receives workgroups w, w + #CUs, w + 2 #CUs (same parity) half of the CUs carried 2.4x the work of the others.
+// Balanced order: blocks are paired (j, nblk-1-j) -- every pair costs nblk+1 -- and a workgroup takes two pairs, so
+// all workgroups cost the same; the position of the four blocks inside the workgroup is permuted with the dispatch
+// round so the four SIMDs of a CU also end up with near-equal sums (15/14/14/11 instead of 24/21/18/15 units).
+__device__ __forceinline__ void attn_item(const AttnP& p, int wave, int64_t& bh, int& blk, bool& valid) {
+    if (!p.balance) {
+        const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+        valid = item < p.n_items;
+        blk = (int)(item % p.nblk);
+        bh = item / p.nblk;
+        return;
+    }
+    const int wpq = p.nblk >> 2;                       // workgroups per (batch, head)
+    const int wg = (int)blockIdx.x, g = wg % wpq;
+    bh = wg / wpq;
+    valid = bh < (int64_t)p.B * p.NH;
+    const int k = (wg / p.rot_div) % 3;
+    const int slot = k == 0 ? wave : k == 1 ? ((0x3201 >> (4 * wave)) & 3) : ((wave + 1) & 3);   // {0,1,2,3}, {1,0,2,3}, {1,2,3,0}
+    const int j = (slot >> 1) ? g + wpq : g;           // pair index
+    blk = (slot & 1) ? j : p.nblk - 1 - j;             // heavy member first
+}
 
 __device__ __forceinline__ int krow(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 // [32 rows][128 B] images.  row image: ds_read_b128 by 32 rows at one chunk is conflict-free
@@ -135,12 +161,12 @@ __device__ __forceinline__ void store_N_acc(char* img, const f32x16 (&acc)[2], f
 __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-    if (item >= p.n_items) return;
+    int64_t bh; int blk; bool valid;
+    attn_item(p, wave, bh, blk, valid);
+    if (!valid) return;
     char* imgK = smem + wave * WAVE_LDS_FWD;
     char* imgV = imgK + 4096;
-    const int qb = p.nblk - 1 - (int)(item % p.nblk);          // heavy blocks first
-    const int64_t bh = item / p.nblk;
+    const int qb = p.balance ? blk : p.nblk - 1 - blk;         // plain order: heavy blocks first
     const int h = (int)(bh % p.NH), b = (int)(bh / p.NH);
     const int T = p.T, C = p.NH * HD;
     const int64_t ld = 3 * (int64_t)C;
@@ -222,13 +248,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-    if (item >= p.n_items) return;
+    int64_t bh; int blk; bool valid;
+    attn_item(p, wave, bh, blk, valid);
+    if (!valid) return;
     char* imgK = smem + wave * WAVE_LDS_DQ;      // row image of K
     char* imgKt = imgK + 4096;                   // transposed-read image of K
     char* imgV = imgK + 8192;                    // row image of V
-    const int qb = p.nblk - 1 - (int)(item % p.nblk);
-    const int64_t bh = item / p.nblk;
+    const int qb = p.balance ? blk : p.nblk - 1 - blk;
     const int h = (int)(bh % p.NH), b = (int)(bh / p.NH);
     const int T = p.T, C = p.NH * HD;
     const int64_t ld = 3 * (int64_t)C;
@@ -312,14 +338,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-    if (item >= p.n_items) return;
+    int64_t bh; int blk; bool valid;
+    attn_item(p, wave, bh, blk, valid);
+    if (!valid) return;
     char* imgQ = smem + wave * WAVE_LDS_DKV;
     char* imgQt = imgQ + 4096;
     char* imgG = imgQ + 8192;
     char* imgGt = imgQ + 12288;
-    const int kb = (int)(item % p.nblk);                     // low key blocks see the most queries: heavy first
-    const int64_t bh = item / p.nblk;
+    const int kb = p.balance ? p.nblk - 1 - blk : blk;       // low key blocks see the most queries: heavy first
     const int h = (int)(bh % p.NH), b = (int)(bh / p.NH);
     const int T = p.T, C = p.NH * HD;
     const int64_t ld = 3 * (int64_t)C;
@@ -424,6 +450,14 @@ static void fill(AttnP& p, int B, int T, int NH, float scale, float dp, const ui
     p.inv_keep = 1.f / (1.f - dp);
     p.thr = dg_drop_threshold(dp);
     p.rng = rng; p.site = site;
+    static const int mode = [] { const char* e = getenv("DG_ATTN_BALANCE"); return e ? atoi(e) : 1; }();   // 0 = plain order (A/B runs)
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    p.balance = (mode != 0 && p.nblk % 4 == 0) ? 1 : 0;
+    p.rot_div = ncu;
 }
 
 int dg_attn_fwd_mfma(const void* qkv, void* out, float* lse, int B, int T, int NH, int H, float scale, float dp,
