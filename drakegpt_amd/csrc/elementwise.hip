@@ -329,12 +329,62 @@ extern "C" int dg_dropout_bwd_cast(const float* dy, int64_t lddy, void* g, int64
     return DG_OK;
 }
 
+// Column sums of a bf16 matrix (bias gradients of the hidden FFN layer: [16384, 1536], 50 MB): 16-byte loads, 8 rows
+// in flight per lane, 4 waves per 512-column strip combined in a fixed order.  (The generic kernel above reads
+// 8 bytes per lane per row and ran at 3.8 TB/s.)
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda, int M, int N,
+                                                          float* __restrict__ part, int64_t part_stride, int rows_per) {
+    __shared__ float red[4][512];
+    const int lane = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.y * 512 + lane * 8;
+    const int m_begin = blockIdx.x * rows_per;
+    int m_end = m_begin + rows_per; if (m_end > M) m_end = M;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (c < N) {                                       // N % 8 == 0: a lane's 8 columns are all inside or all outside
+        const bf16_t* col = A + c;
+        int m = m_begin + ty;
+        for (; m + 28 < m_end; m += 32) {
+            bf16x8 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = *(const bf16x8*)(col + (int64_t)(m + 4 * u) * lda);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)t[u][j];
+        }
+        for (; m < m_end; m += 4) {
+            const bf16x8 t = *(const bf16x8*)(col + (int64_t)m * lda);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)t[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[ty][lane * 8 + j] = acc[j];
+    __syncthreads();
+    if (ty == 0 && c < N) {
+        float* o = part + (int64_t)blockIdx.x * part_stride + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cc = lane * 8 + j;
+            o[j] = red[0][cc] + red[1][cc] + red[2][cc] + red[3][cc];
+        }
+    }
+}
+
 extern "C" int dg_colsum(const void* A, int64_t lda, int dtype, float* part, int64_t part_stride,
                          int n_partials, int M, int N, void* stream) {
     if (!A || !part || M <= 0 || N <= 0 || n_partials <= 0) return DG_ERR_ARG;
     int rows_per = rows_per_partial(M, n_partials);
     dim3 grid(n_partials, (N + 255) / 256), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == DG_BF16 && N % 8 == 0 && lda % 8 == 0 && dg_aligned16(A)) {
+        hipLaunchKernelGGL(colsum_bf16_kernel, dim3(n_partials, (N + 511) / 512), dim3(256), 0, s, (const bf16_t*)A, lda, M, N, part,
+                           part_stride, rows_per);
+        DG_LAUNCH_CHECK();
+        return DG_OK;
+    }
     if (dtype == DG_BF16)
         hipLaunchKernelGGL((dropbwd_cast_kernel<bf16_t, float, false>), grid, block, 0, s, (const bf16_t*)A, lda, (float*)nullptr, (int64_t)0, M, N, 1.f, 0u, (const uint32_t*)nullptr, 0u, (const float*)nullptr, (int64_t)0, part, part_stride, rows_per);
     else if (dtype == DG_F32)

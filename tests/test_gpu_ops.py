@@ -293,6 +293,20 @@ def test_casts_and_colsum(dev):
     assert rel(cs, dy.bfloat16().double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,G,ld", [(16384, 1536, 256, 1536), (1000, 384, 31, 392), (517, 80, 16, 80), (64, 1032, 1, 1040), (300, 84, 7, 88)])
+def test_colsum_bf16(dev, M, N, G, ld):
+    """the 16-byte-load kernel (N % 8 == 0) and the generic one (N = 84), ragged row chunks, padded leading dimension"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.zeros(M, ld, dtype=torch.bfloat16)
+    A[:, :N] = torch.randn(M, N, generator=g).bfloat16()
+    part = torch.full((G, N), float("nan"), device=dev)
+    ops.colsum(A.to(dev)[:, :N], part, N, G)
+    cs = torch.empty(N, device=dev)
+    ops.reduce_partials(part, N, G, cs, N)
+    assert rel(cs, A[:, :N].double().sum(0)) < 1e-5
+
+
 def test_adamw_matches_oracle(dev):
     from oracle import drake_ref as R
     ops = _ops()

@@ -226,6 +226,110 @@ __global__ __launch_bounds__(512) void store_kernel(char* dst, size_t panel_byte
     if (tid == 0) out[blockIdx.x] = t1 - t0;
 }
 
+
+// ---- TN (dW) K step: fragments come from ds_read_b64_tr_b16 pairs out of [64 r][128 cols] images
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int tn_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+__device__ __forceinline__ u32x4 tn_frag(const char* tile, int r0, int col0, int lane) {
+    const int i = lane & 15, q = i >> 2, pp = i & 3;
+    const int c0 = col0 >> 3;
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const char* a0 = tile + tn_off(r0 + q, c0 + (pp >> 1)) + 8 * (pp & 1);
+    const char* a1 = tile + tn_off(r0 + 4 + q, c0 + (pp >> 1)) + 8 * (pp & 1);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a1);
+    bf16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(u32x4, v);
+}
+template <int WM, int WN, int NW>      // NW MFMA waves; wave tile WM*16 x WN*16 of a 128 x 128 (NW=8, 2x4) or (NW=4, 4x4) tile
+__global__ __launch_bounds__(768) void tn_step_kernel(const char* src, size_t region, int iters, int with_dma, long long* out, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const char* base = src + (size_t)((blockIdx.x >> 3) % 4) * region;
+    if (wave >= NW) {
+        if (wave >= NW + 4) return;
+        const int lw = wave - NW;
+        const int prow = lane >> 4, slot = lane & 15;
+        for (int it = 0; it < iters; ++it) {
+            if (with_dma) {
+                char* db = lds + ((it + 3) & 3) * 32768 + (4 * lw) * 1024;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int q = 4 * lw + i, row = 4 * q + prow;
+                    const char* g = base + (size_t)((it % 6) * 64 + row) * 768 + slot * 16;
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(db + i * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(g + 256), (lptr_t)(db + 16384 + i * 1024), 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    const int fg = lane >> 4;
+    constexpr int NWN = 128 / (WN * 16);
+    const int wp = wave / NWN, wq = wave % NWN;
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 fa0[WM], fb0[WN], fa1[WM], fb1[WN];
+    auto rd = [&](u32x4 (&fa)[WM], u32x4 (&fb)[WN], const char* buf, int ks) {
+        const int r0 = ks * 32 + fg * 8;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) fa[i] = tn_frag(buf, r0, wp * WM * 16 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) fb[j] = tn_frag(buf + 16384, r0, wq * WN * 16 + j * 16, lane);
+    };
+    auto mm = [&](const u32x4 (&fa)[WM], const u32x4 (&fb)[WN]) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+    };
+    rd(fa0, fb0, lds, 0);
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        rd(fa1, fb1, lds + (it & 3) * 32768, 1);
+        mm(fa0, fb0);
+        __builtin_amdgcn_s_barrier();
+        rd(fa0, fb0, lds + ((it + 1) & 3) * 32768, 0);
+        mm(fa1, fb1);
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) a += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (a == 123.456f) sink[0] = a;
+    if (lane == 0 && wave == 0) out[blockIdx.x] = t1 - t0;
+}
+template <int WM, int WN, int NW>
+static void run_tn(const char* name, const char* src, size_t region, int iters, long long* out, float* sink) {
+    CHECK(hipFuncSetAttribute((const void*)tn_step_kernel<WM, WN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    std::vector<long long> h(256);
+    for (int with_dma = 0; with_dma < 2; ++with_dma) {
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        float ms = 0.f;
+        const int big = iters * 20;
+        for (int rep = 0; rep < 2; ++rep) {
+            CHECK(hipEventRecord(e0));
+            tn_step_kernel<WM, WN, NW><<<256, 64 * (NW + 4), 131072>>>(src, region, big, with_dma, out, sink);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        CHECK(hipMemcpy(h.data(), out, 256 * sizeof(long long), hipMemcpyDeviceToHost));
+        double avg = 0; for (int i = 0; i < 256; ++i) avg += (double)h[i]; avg /= 256;
+        printf("tn-step %s dma=%d: %7.1f cycles, %.1f ns per 128x128x64 step -> %.0f TFLOP/s\n", name, with_dma, avg / big, ms * 1e6 / big,
+               256.0 * 2 * 128 * 128 * 64 * big / (ms * 1e-3) / 1e12);
+    }
+}
+
 int main(int argc, char** argv) {
     const int iters = 600;
     const int row_stride = 768;                       // K = 384 bf16
@@ -270,6 +374,9 @@ int main(int argc, char** argv) {
             }
         CHECK(hipFree(dst));
     }
+    run_tn<2, 4, 8>("8 waves of 32x64", src, region, iters, out, sink);
+    run_tn<4, 4, 4>("4 waves of 64x64", src, region, iters, out, sink);
+    run_tn<4, 4, 8>("8 waves of 64x64 (256x128 tile: halve the printed time per 128x128x64)", src, region, iters, out, sink);
     run_step<2, 4>("8 waves of 32x64", 8, src, region, row_stride, iters, out, sink);
     if (argc > 1) return 0;
     for (int mode = 0; mode < 2; ++mode)
