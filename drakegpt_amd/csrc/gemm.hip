@@ -335,9 +335,15 @@ __global__ __launch_bounds__(512) void gemm_nt_glds_kernel(NtParams p) {
 // serialise (they dominated at K = 384: six K steps per tile).  The accumulators are kept
 // TRANSPOSED (mfma(B, A)): a lane then owns 4 consecutive output columns of one row, so the
 // epilogue stores 8/16-byte pieces straight from registers and needs no LDS staging at all.
-template <typename TO, bool PF>
+// NJ = 16-column MFMA blocks per wave: 4 -> 128 x 128 tiles (wave tile 32 x 64), 6 -> 128 x 192 tiles (32 x 96).  The wide tile
+// makes N = 384 / 1152 / 1536 an exact number of rounds on 256 CUs at M = 16384 (256 / 768 / 1024 tiles; the square tile needs
+// 384 = 1.5 rounds for N = 384) and amortises the per-tile epilogue and barrier costs over 1.5x the MFMA work.
+template <typename TO, bool PF, int NJ>
 __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE + 8 * 4096];   // 4 stages + a 4 KB epilogue slice per wave = 160 KB
+    constexpr int BNW = NJ * 32;                               // tile width
+    constexpr int STAGE = 16384 + BNW * 128;                   // A [128][128 B] + B [BNW][128 B]
+    constexpr int PPA = WS_PPL, PPB = BNW / 8 / WS_NLOAD;      // 1 KB pieces per loader wave per stage
+    __shared__ __attribute__((aligned(16))) char lds[GL_NST * STAGE];          // 128 KB / 160 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int G = gridDim.x;
@@ -349,44 +355,48 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     const int chunk = slot ^ prow;
     const bool loader = wave >= 8;                 // waves 8..11 only move data
     const int lw = wave - 8;
-    const char* srcA[WS_PPL];
-    const char* srcB[WS_PPL];
+    const char* srcA[PPA];
+    const char* srcB[PPB];
     auto set_src = [&](int ti) {
         const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
-        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BNW;
 #pragma unroll
-        for (int i = 0; i < WS_PPL; ++i) {
-            const int row = (WS_PPL * lw + i) * 8 + prow;
-            int gm = m0 + row; if (gm > p.M - 1) gm = p.M - 1;
-            int gn = n0 + row; if (gn > p.N - 1) gn = p.N - 1;
+        for (int i = 0; i < PPA; ++i) {
+            int gm = m0 + (PPA * lw + i) * 8 + prow; if (gm > p.M - 1) gm = p.M - 1;
             srcA[i] = p.A + (int64_t)gm * p.lda_b + chunk * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < PPB; ++i) {
+            int gn = n0 + (PPB * lw + i) * 8 + prow; if (gn > p.N - 1) gn = p.N - 1;
             srcB[i] = p.B + (int64_t)gn * p.ldb_b + chunk * 16;
         }
     };
     int iss_tile = 0, iss_kt = 0;
     auto issue = [&](int g) {
-        char* base = lds + (g & (GL_NST - 1)) * GL_STAGE + (WS_PPL * lw) * 1024;
+        char* base = lds + (g & (GL_NST - 1)) * STAGE;
         const int64_t koff = (int64_t)iss_kt * 128;
-        if (!((p.dbg == 1 || p.dbg == 4) && g > 0))             // ablation: no operand traffic after the first stage
+        if (!((p.dbg == 1 || p.dbg == 4) && g > 0)) {           // ablation: no operand traffic after the first stage
 #pragma unroll
-        for (int i = 0; i < WS_PPL; ++i) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + koff), (lptr_t)(base + 16384 + i * 1024), 16, 0, 0);
+            for (int i = 0; i < PPA; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + (PPA * lw + i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < PPB; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + koff), (lptr_t)(base + 16384 + (PPB * lw + i) * 1024), 16, 0, 0);
         }
         if (++iss_kt == nk) { iss_kt = 0; if (++iss_tile < my_tiles) set_src(iss_tile); }
     };
     if (loader) {
-        // ---- loader role: 8 LDS-DMA pieces per stage per wave; stages g+1.. stay in flight behind counted waits
+        // ---- loader role: PPA + PPB LDS-DMA pieces per stage per wave; stages g+1.. stay in flight behind counted waits
         set_src(0);
         const int npre = total < GL_NST - 1 ? total : GL_NST - 1;
         for (int g = 0; g < npre; ++g) issue(g);
-        if (npre >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * WS_PPL) : "memory");
-        else if (npre == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * WS_PPL) : "memory");
+        if (npre >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (PPA + PPB)) : "memory");
+        else if (npre == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPA + PPB) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // stage 0 published
         for (int g = 0; g + 1 < total; ++g) {
             int issued = g + GL_NST - 1; if (issued > total) issued = total;
-            if (issued - (g + 2) >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * WS_PPL) : "memory");   // stage g+1 landed, g+2 may fly
+            if (issued - (g + 2) >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPA + PPB) : "memory");   // stage g+1 landed, g+2 may fly
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                          // publishes stage g+1; stage g-1's buffer is free
             if (g + GL_NST - 1 < total) issue(g + GL_NST - 1);
@@ -394,25 +404,25 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
         return;
     }
 
-    f32x4 acc[2][4];
+    f32x4 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fg = lane >> 4;
-    auto read_frags = [&](u32x4 (&fa)[2], u32x4 (&fb)[4], const char* buf, int ks) {
-        const int ka = nt_lds_off(wm * 32 + fr, ks * 4 + fg), kb = nt_lds_off(wn * 64 + fr, ks * 4 + fg);
+    auto read_frags = [&](u32x4 (&fa)[2], u32x4 (&fb)[NJ], const char* buf, int ks) {
+        const int ka = nt_lds_off(wm * 32 + fr, ks * 4 + fg), kb = nt_lds_off(wn * (NJ * 16) + fr, ks * 4 + fg);
 #pragma unroll
         for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(buf + ka + i * 16 * 128);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(buf + 16384 + kb + j * 16 * 128);
+        for (int j = 0; j < NJ; ++j) fb[j] = *(const u32x4*)(buf + 16384 + kb + j * 16 * 128);
     };
-    auto mma_all = [&](const u32x4 (&fa)[2], const u32x4 (&fb)[4]) {      // transposed: D rows = n, cols = m
+    auto mma_all = [&](const u32x4 (&fa)[2], const u32x4 (&fb)[NJ]) {     // transposed: D rows = n, cols = m
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
+            for (int j = 0; j < NJ; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
     };
     uint32_t key = 0;
     if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
@@ -423,18 +433,18 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     // trip per 16-row block with the matrix cores idle (55 us -> 42 us in the step).  Kept out of the other
     // variants: the extra live registers slow their K loop by ~8% (measured).
     constexpr int PF_AHEAD = 2;
-    bf16x8 pf_mask[2][2];
-    f32x4 pf_bias[2][2];
+    bf16x8 pf_mask[NJ / 2][2];
+    f32x4 pf_bias[NJ / 2][2];
     bool pf_ok = false;
     auto prefetch_operands = [&](int ti) {
         if constexpr (PF) {
             const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
-            const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-            pf_ok = vok && (m0 + BM <= p.M) && (n0 + BN <= p.N);
+            const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BNW;
+            pf_ok = vok && (m0 + BM <= p.M) && (n0 + BNW <= p.N);
             if (!pf_ok) return;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int col = n0 + wn * 64 + (2 * q + (fg & 1)) * 16 + (fg >> 1) * 8;
+            for (int q = 0; q < NJ / 2; ++q) {
+                const int col = n0 + wn * (NJ * 16) + (2 * q + (fg & 1)) * 16 + (fg >> 1) * 8;
                 if (p.bias) { pf_bias[q][0] = *(const f32x4*)(p.bias + col); pf_bias[q][1] = *(const f32x4*)(p.bias + col + 4); }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -449,10 +459,10 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     // consecutive columns starting at (2q + (fg&1))*16 + (fg>>1)*8.
     auto epilogue = [&](int ti) -> bool {
         const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
-        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BNW;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int col = n0 + wn * 64 + (2 * q + (fg & 1)) * 16 + (fg >> 1) * 8;
+        for (int q = 0; q < NJ / 2; ++q) {
+            const int col = n0 + wn * (NJ * 16) + (2 * q + (fg & 1)) * 16 + (fg >> 1) * 8;
             const bool full = vok && (col + 7 < p.N);
             float bv[8];
 #pragma unroll
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                 }
             }
         }
-        return vok && (m0 + BM <= p.M) && (n0 + BN <= p.N);
+        return vok && (m0 + BM <= p.M) && (n0 + BNW <= p.N);
     };
 
     int nstamp = 0;
@@ -555,19 +565,19 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     };
     stamp();
     // ---- MFMA role
-    u32x4 fa0[2], fb0[4], fa1[2], fb1[4];
+    u32x4 fa0[2], fb0[NJ], fa1[2], fb1[NJ];
     __builtin_amdgcn_s_barrier();                                  // stage 0 published by the loaders
     read_frags(fa0, fb0, lds, 0);
     stamp();
     int kt = 0, tile_i = 0;
     const int pf_at = nk > PF_AHEAD ? nk - 1 - PF_AHEAD : 0;
     for (int g = 0; g < total; ++g) {
-        const char* buf = lds + (g & (GL_NST - 1)) * GL_STAGE;
+        const char* buf = lds + (g & (GL_NST - 1)) * STAGE;
         if (PF && kt == pf_at) prefetch_operands(tile_i);
         if (p.dbg != 2) { read_frags(fa1, fb1, buf, 1); mma_all(fa0, fb0); }
         if (g + 1 < total) {
             __builtin_amdgcn_s_barrier();                          // stage g+1 is visible; nothing to wait for here
-            if (p.dbg != 2) read_frags(fa0, fb0, lds + ((g + 1) & (GL_NST - 1)) * GL_STAGE, 0);
+            if (p.dbg != 2) read_frags(fa0, fb0, lds + ((g + 1) & (GL_NST - 1)) * STAGE, 0);
         }
         if (p.dbg != 2) mma_all(fa1, fb1);
         stamp();
@@ -1277,9 +1287,22 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
         dim3 pgrid(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
         const bool pf = a->out_dtype == DG_BF16 && a->relu_mask && !a->residual && p.vec_ok && p.mask_vec_ok && (a->ldmask % 8 == 0) &&
                         dg_aligned16(a->relu_mask) && (a->ldc % 8 == 0) && dg_aligned16(a->C) && (!a->bias || dg_aligned16(a->bias));
-        if (pf) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true>), pgrid, dim3(512 + 64 * WS_NLOAD), 0, s, p);
-        else if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false>), pgrid, dim3(512 + 64 * WS_NLOAD), 0, s, p);
-        else hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false>), pgrid, dim3(512 + 64 * WS_NLOAD), 0, s, p);
+        static const int wide_mode = [] { const char* e = getenv("DG_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // 0 = square tiles only (A/B runs)
+        const bool wide = wide_mode && a->N % 192 == 0 && !pf;    // 128 x 192 tiles (the mask-prefetch variant would spill)
+        if (wide) {
+            p.tiles_n = a->N / 192;
+            p.n_tiles = tiles_m * p.tiles_n;
+            pgrid = dim3(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
+        }
+        const dim3 wsb(512 + 64 * WS_NLOAD);
+        if (wide) {
+            if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, 6>), pgrid, wsb, 0, s, p);
+            else hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, 6>), pgrid, wsb, 0, s, p);
+        } else {
+            if (pf) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true, 4>), pgrid, wsb, 0, s, p);
+            else if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, 4>), pgrid, wsb, 0, s, p);
+            else hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, 4>), pgrid, wsb, 0, s, p);
+        }
     } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 2) {
         if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16_t>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_nt_glds_kernel<float>), grid, dim3(512), 0, s, p);

@@ -45,10 +45,12 @@ def test_gemm_nt_asymmetric_identity(dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_gemm_nt_epilogue(dev, dtype):
+@pytest.mark.parametrize("M,N,K", [(320, 200, 128), (300, 384, 128), (1100, 1152, 192), (256, 1536, 128), (40000, 192, 128)])
+def test_gemm_nt_epilogue(dev, dtype, M, N, K):
+    """every epilogue option on: square tiles (N = 200), 128 x 192 tiles (N % 192 == 0) with ragged M, several tiles
+    per workgroup (40000 x 192: 313 tiles), and -- bf16 output with a 16-byte-aligned mask -- the mask-prefetch variant"""
     from oracle import rng_ref
     ops = _ops()
-    M, N, K = 320, 200, 128
     g = torch.Generator().manual_seed(1)
     A = torch.randn(M, K, generator=g).to(dtype)
     B = torch.randn(N, K, generator=g).to(dtype)
@@ -65,6 +67,8 @@ def test_gemm_nt_epilogue(dev, dtype):
     out = ops.gemm_nt(A.to(dev), B.to(dev), torch.float32, relu_mask=mask.to(dev))
     ref = (A.double() @ B.double().T) * (mask.double() > 0)
     assert rel(out, ref) < 2e-6
+    out = ops.gemm_nt(A.to(dev), B.to(dev), dtype, relu_mask=mask.to(dev), bias=bias.to(dev))
+    assert rel(out, acc * (mask.double() > 0)) < tol
     # bias + dropout + residual, fp32 out; mask recomputed on the host from the same hash
     seed, step, site, p = 1234, 5, 9, 0.25
     rng = ops.new_rng_state(seed, dev, step)
