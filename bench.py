@@ -190,8 +190,8 @@ def kernel_roofline(eng, offsets, peak_tflops):
         r = real_nt(A, Bm, out_dtype, **kw)
         to = "bf16" if out_dtype == torch.bfloat16 else "float"
         if A.dtype == torch.bfloat16 and K % 64 == 0 and K >= 128:        # dispatch rule of dg_gemm_nt
-            pf = out_dtype == torch.bfloat16 and kw.get("relu_mask") is not None and kw.get("residual") is None
-            nj = 6 if (N % 192 == 0 and not pf) else 4                     # 128 x 192 tiles when they divide N
+            pf = kw.get("sign_bits") is not None                           # mask-bit prefetch variant
+            nj = 6 if N % 192 == 0 else 4                                  # 128 x 192 tiles when they divide N
             sym = f"gemm_nt_ws_kernel<{to},{'true' if pf else 'false'},{nj}>"
         else:
             sym = f"gemm_nt_kernel<{'bf16' if A.dtype == torch.bfloat16 else 'float'},{to}>"

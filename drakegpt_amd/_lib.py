@@ -34,6 +34,9 @@ class GemmNtArgs(C.Structure):
         ("dropout_p", C.c_float),
         ("rng_state", C.c_void_p),
         ("site", C.c_uint32),
+        ("sign_bits_out", C.c_void_p),
+        ("sign_bits", C.c_void_p),
+        ("sign_bits_bytes", C.c_int64),
     ]
 
 
@@ -60,6 +63,8 @@ SIGNATURES = {
     "dg_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "dg_layernorm_bwd_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _vp, _u32, _vp, _vp],
     "dg_gemm_nt": [C.POINTER(GemmNtArgs), _vp],
+    "dg_gemm_nt_sign_bits_supported": [C.POINTER(GemmNtArgs)],
+    "dg_gemm_nt_sign_bits_bytes": [_i, _i],
     "dg_gemm_tn": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp],
     "dg_gemm_tn_grouped": [C.POINTER(TnProblem), _i, _i, _vp],
     "dg_reduce_partials": [_vp, _i64, _i, _vp, _i64, _vp],
@@ -91,6 +96,7 @@ def _load() -> C.CDLL:
             raise RuntimeError(f"drakegpt_amd: {LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.dg_gemm_nt_sign_bits_bytes.restype = C.c_int64
     lib.dg_error_string.argtypes = [C.c_int]
     lib.dg_error_string.restype = C.c_char_p
     v = lib.dg_version()

@@ -60,6 +60,7 @@ struct NtParams {
     const float* bias;
     int relu;
     const void* relu_mask; int64_t ldmask;
+    unsigned char* bits_out; const unsigned char* bits_in;   // one-bit-per-element ReLU mask, lane-ordered (wave-specialised kernel only)
     const float* residual; int64_t ldr;
     float inv_keep; uint32_t thr; int drop;
     const uint32_t* rng_state; uint32_t site;
@@ -428,13 +429,11 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
     TO* Cp = (TO*)p.C;
     const bool vok = p.vec_ok && (((p.ldc * sizeof(TO)) & 15) == 0) && (((uintptr_t)Cp & 15) == 0);
-    // PF variant (bf16 output with a ReLU mask: dX of FFN2): the mask and bias of an interior tile are fetched into
-    // registers PF_AHEAD K steps before the tile ends.  Loaded inside the epilogue they cost a dependent HBM round
-    // trip per 16-row block with the matrix cores idle (55 us -> 42 us in the step).  Kept out of the other
-    // variants: the extra live registers slow their K loop by ~8% (measured).
+    // PF variant (sign_bits input: dX of FFN2): the mask bytes of an interior tile are fetched into registers
+    // PF_AHEAD K steps before the tile ends (one byte per lane and 16-row block).  Loaded inside the epilogue they cost a
+    // dependent HBM round trip per block with the matrix cores idle.
     constexpr int PF_AHEAD = 2;
-    bf16x8 pf_mask[NJ / 2][2];
-    f32x4 pf_bias[NJ / 2][2];
+    unsigned char pf_bits[NJ / 2][2];
     bool pf_ok = false;
     auto prefetch_operands = [&](int ti) {
         if constexpr (PF) {
@@ -445,11 +444,9 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
 #pragma unroll
             for (int q = 0; q < NJ / 2; ++q) {
                 const int col = n0 + wn * (NJ * 16) + (2 * q + (fg & 1)) * 16 + (fg >> 1) * 8;
-                if (p.bias) { pf_bias[q][0] = *(const f32x4*)(p.bias + col); pf_bias[q][1] = *(const f32x4*)(p.bias + col + 4); }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int row = m0 + wm * 32 + i * 16 + fr;
-                    pf_mask[q][i] = *(const bf16x8*)((const bf16_t*)p.relu_mask + (int64_t)row * p.ldmask + col);
+                    pf_bits[q][i] = p.bits_in[((((int64_t)tile * 8 + wave) * (NJ / 2) + q) * 2 + i) * 64 + lane];
                 }
             }
         }
@@ -467,10 +464,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
             float bv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-            if (PF && p.bias && pf_ok) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { bv[e] = pf_bias[q][0][e]; bv[4 + e] = pf_bias[q][1][e]; }
-            } else if (p.bias && col < p.N) {
+            if (p.bias && col < p.N) {
                 if (full) {
                     const f32x4 b0 = *(const f32x4*)(p.bias + col), b1 = *(const f32x4*)(p.bias + col + 4);
 #pragma unroll
@@ -502,12 +496,16 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
+                if (p.bits_in) {
+                    unsigned bm;
+                    if (PF && pf_ok) bm = pf_bits[q][i];
+                    else bm = p.bits_in[((((int64_t)tile * 8 + wave) * (NJ / 2) + q) * 2 + i) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ((bm >> e) & 1u) ? v[e] : 0.f;
+                }
                 if (p.relu_mask) {
                     const bf16_t* mp = (const bf16_t*)p.relu_mask + (int64_t)row * p.ldmask + col;
-                    if (PF && pf_ok) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (float)pf_mask[q][i][e] > 0.f ? v[e] : 0.f;
-                    } else if (full && p.mask_vec_ok) {
+                    if (full && p.mask_vec_ok) {
                         const bf16x4 m0v = *(const bf16x4*)mp, m1v = *(const bf16x4*)(mp + 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -536,6 +534,12 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                         for (int e = 0; e < 8; ++e)
                             if (col + e < p.N) v[e] += rp[e];
                     }
+                }
+                if (p.bits_out) {                              // N % 8 == 0: the lane's 8 columns are all inside
+                    unsigned bm = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bm |= (v[e] > 0.f ? 1u : 0u) << e;
+                    p.bits_out[((((int64_t)tile * 8 + wave) * (NJ / 2) + q) * 2 + i) * 64 + lane] = (unsigned char)bm;   // 64 contiguous bytes per wave
                 }
                 TO* cp = Cp + (int64_t)row * p.ldc + col;
                 if (full) {
@@ -1236,6 +1240,21 @@ static int dg_num_cus() {
     return v;
 }
 
+extern "C" int dg_gemm_nt_sign_bits_supported(const dg_gemm_nt_args* a) {
+    return a && a->in_dtype == DG_BF16 && a->N > 0 && a->N % 8 == 0 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 0;
+}
+
+// bytes of the lane-ordered bit mask: one bit per element of every (whole) output tile of the kernel that will run
+static bool dg_nt_wide(int N) {
+    static const int wide_mode = [] { const char* e = getenv("DG_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // 0 = square tiles only (A/B runs)
+    return wide_mode && N % 192 == 0;
+}
+extern "C" int64_t dg_gemm_nt_sign_bits_bytes(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    const int bn = dg_nt_wide(N) ? 192 : 128;
+    return (int64_t)((M + BM - 1) / BM) * ((N + bn - 1) / bn) * (BM * bn / 8);
+}
+
 extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return DG_ERR_ARG;
     const int esz = a->in_dtype == DG_BF16 ? 2 : 4;
@@ -1246,6 +1265,10 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
     if (a->K % epc || a->lda % epc || a->ldb % epc || !dg_aligned16(a->A) || !dg_aligned16(a->B)) return DG_ERR_ALIGN;
     if (a->lda < a->K || a->ldb < a->K || a->ldc < a->N) return DG_ERR_ARG;
     if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return DG_ERR_ARG;
+    if (a->sign_bits_out || a->sign_bits) {
+        if (!dg_gemm_nt_sign_bits_supported(a) || a->sign_bits_bytes < dg_gemm_nt_sign_bits_bytes(a->M, a->N) ||
+            (a->sign_bits && a->relu_mask)) return DG_ERR_ARG;
+    }
     NtParams p;
     p.A = (const char*)a->A; p.lda_b = a->lda * esz;
     p.B = (const char*)a->B; p.ldb_b = a->ldb * esz;
@@ -1253,6 +1276,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.bias = a->bias; p.relu = a->relu;
     p.relu_mask = a->relu_mask; p.ldmask = a->ldmask;
+    p.bits_out = a->sign_bits_out; p.bits_in = a->sign_bits;
     p.residual = a->residual; p.ldr = a->ldr;
     p.drop = (a->dropout_p > 0.f && a->rng_state) ? 1 : 0;
     p.inv_keep = 1.f / (1.f - a->dropout_p);
@@ -1285,24 +1309,22 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
         else hipLaunchKernelGGL((gemm_nt_pp_kernel<float>), pgrid, dim3(384), 0, s, p);
     } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 0) {
         dim3 pgrid(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
-        const bool pf = a->out_dtype == DG_BF16 && a->relu_mask && !a->residual && p.vec_ok && p.mask_vec_ok && (a->ldmask % 8 == 0) &&
-                        dg_aligned16(a->relu_mask) && (a->ldc % 8 == 0) && dg_aligned16(a->C) && (!a->bias || dg_aligned16(a->bias));
-        static const int wide_mode = [] { const char* e = getenv("DG_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // 0 = square tiles only (A/B runs)
-        const bool wide = wide_mode && a->N % 192 == 0 && !pf;    // 128 x 192 tiles (the mask-prefetch variant would spill)
+        const bool pf = a->sign_bits != nullptr && p.vec_ok && (!a->bias || dg_aligned16(a->bias)) &&
+                        (a->ldc * (a->out_dtype == DG_BF16 ? 2 : 4)) % 16 == 0 && dg_aligned16(a->C);
+        const bool wide = dg_nt_wide(a->N);                       // 128 x 192 tiles
         if (wide) {
             p.tiles_n = a->N / 192;
             p.n_tiles = tiles_m * p.tiles_n;
             pgrid = dim3(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
         }
         const dim3 wsb(512 + 64 * WS_NLOAD);
-        if (wide) {
-            if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, 6>), pgrid, wsb, 0, s, p);
-            else hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, 6>), pgrid, wsb, 0, s, p);
-        } else {
-            if (pf) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true, 4>), pgrid, wsb, 0, s, p);
-            else if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, 4>), pgrid, wsb, 0, s, p);
-            else hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, 4>), pgrid, wsb, 0, s, p);
-        }
+#define DG_WS_LAUNCH(NJ_) do { \
+            if (pf && a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true, NJ_>), pgrid, wsb, 0, s, p); \
+            else if (pf) hipLaunchKernelGGL((gemm_nt_ws_kernel<float, true, NJ_>), pgrid, wsb, 0, s, p); \
+            else if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, NJ_>), pgrid, wsb, 0, s, p); \
+            else hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, NJ_>), pgrid, wsb, 0, s, p); } while (0)
+        if (wide) DG_WS_LAUNCH(6); else DG_WS_LAUNCH(4);
+#undef DG_WS_LAUNCH
     } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 2) {
         if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16_t>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_nt_glds_kernel<float>), grid, dim3(512), 0, s, p);

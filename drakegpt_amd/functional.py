@@ -77,20 +77,20 @@ class FFNFn(torch.autograd.Function):
         run = _run(act, rng)
         x2d = x.contiguous().view(B * T, Cd)
         y, saved = S.ffn_fwd(run, x2d, ln_w, ln_b, w1, b1, w2, b2, residual, p, layer)
-        x2d_s, h, mean, rstd, f = saved
-        ctx.save_for_backward(x2d_s, h, mean, rstd, f, ln_w, w1, w2, rng)
+        x2d_s, h, mean, rstd, f, bits = saved
+        ctx.save_for_backward(x2d_s, h, mean, rstd, f, ln_w, w1, w2, rng, bits)
         ctx.cfg = (act, residual, B, T, p, layer)
         return y.view(B, T, -1)
 
     @staticmethod
     def backward(ctx, dy):
-        x2d, h, mean, rstd, f, ln_w, w1, w2, rng = ctx.saved_tensors
+        x2d, h, mean, rstd, f, ln_w, w1, w2, rng, bits = ctx.saved_tensors
         act, residual, B, T, p, layer = ctx.cfg
         run = _run(act, rng)
         dy2 = dy.contiguous().view(B * T, -1)
         sink = S.LocalSink(B * T, dy.device)
         keys = {"w1": "w1", "b1": "b1", "w2": "w2", "b2": "b2", "ln_w": "ln_w", "ln_b": "ln_b"}
-        dx = S.ffn_bwd(run, (x2d, h, mean, rstd, f), dy2, ln_w, w1, w2, residual, p, layer, sink, keys,
+        dx = S.ffn_bwd(run, (x2d, h, mean, rstd, f, bits), dy2, ln_w, w1, w2, residual, p, layer, sink, keys,
                        need_dx=ctx.needs_input_grad[0])
         g = sink.finish()
         return (None if dx is None else dx.view(B, T, -1), g.get("ln_w"), g.get("ln_b"), g["w1"], g["b1"], g.get("w2"),

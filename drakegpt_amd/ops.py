@@ -158,8 +158,10 @@ def layernorm_bwd_fused_supported(C: int) -> bool:
 def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] = None, K: Optional[int] = None,
             bias: Optional[Tensor] = None, relu: bool = False, relu_mask: Optional[Tensor] = None,
             residual: Optional[Tensor] = None, dropout_p: float = 0.0, rng_state: Optional[Tensor] = None,
-            site: int = 0, out: Optional[Tensor] = None) -> Tensor:
-    """out[M,N] = epilogue(A[M,K] @ Bm[N,K]^T).  A/Bm may carry padding columns beyond K (ld > K)."""
+            site: int = 0, out: Optional[Tensor] = None, sign_bits_out: Optional[Tensor] = None,
+            sign_bits: Optional[Tensor] = None) -> Tensor:
+    """out[M,N] = epilogue(A[M,K] @ Bm[N,K]^T).  A/Bm may carry padding columns beyond K (ld > K).
+    sign_bits_out / sign_bits: opaque uint8 buffer (new_sign_bits) holding one bit per element, out > 0."""
     _chk(A, "A", contiguous=False)
     _chk(Bm, "B", contiguous=False)
     if A.dtype != Bm.dtype:
@@ -190,8 +192,26 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
     a.dropout_p = float(dropout_p)
     a.rng_state = _p(rng_state) if dropout_p > 0.0 else None
     a.site = site
+    for name, t in (("sign_bits_out", sign_bits_out), ("sign_bits", sign_bits)):
+        if t is not None:
+            _chk(t, name, torch.uint8)
+            setattr(a, name, _p(t))
+            a.sign_bits_bytes = t.numel()
     check(lib.dg_gemm_nt(C.byref(a), _stream()), "dg_gemm_nt")
     return out
+
+
+def gemm_nt_sign_bits_supported(dtype: torch.dtype, N: int, K: int) -> bool:
+    """can dg_gemm_nt emit / consume the one-bit-per-element ReLU mask for this problem?"""
+    a = GemmNtArgs()
+    a.M, a.N, a.K = 128, N, K
+    a.in_dtype = a.out_dtype = dt_code(dtype)
+    return bool(lib.dg_gemm_nt_sign_bits_supported(C.byref(a)))
+
+
+def new_sign_bits(M: int, N: int, device) -> Tensor:
+    """buffer for gemm_nt(sign_bits_out=...) of an [M, N] output"""
+    return torch.empty(int(lib.dg_gemm_nt_sign_bits_bytes(M, N)), dtype=torch.uint8, device=device)
 
 
 def gemm_tn(A: Tensor, Bm: Tensor, out_part: Tensor, split_stride: int, n_splits: int, P: int, Q: int, ldo: Optional[int] = None) -> None:

@@ -224,17 +224,21 @@ def ffn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor
     if w2 is None:
         # FeedForward: Linear(C,C) + ReLU (ref: src/model_component.py:118-121)
         y = ops.gemm_nt(h, run.weights.fwd(w1), torch.float32, bias=b1, relu=True)
-        return y, (x2d, h, mean, rstd, y)
-    f = ops.gemm_nt(h, run.weights.fwd(w1), run.act, bias=b1, relu=True)
+        return y, (x2d, h, mean, rstd, y, None)
+    # the ReLU mask for backward travels as one bit per element next to f (1/16 of the bytes the dX GEMM would re-read)
+    bits = None
+    if ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w1.shape[1]) and ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w2.shape[0]):
+        bits = ops.new_sign_bits(h.shape[0], w1.shape[0], h.device)
+    f = ops.gemm_nt(h, run.weights.fwd(w1), run.act, bias=b1, relu=True, sign_bits_out=bits)
     y = ops.gemm_nt(f, run.weights.fwd(w2), torch.float32, bias=b2, dropout_p=run.p(p), rng_state=run.rng,
                     site=site_ffn(layer), residual=x2d if residual else None)
-    return y, (x2d, h, mean, rstd, f)
+    return y, (x2d, h, mean, rstd, f, bits)
 
 
 def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2: Optional[Tensor], residual: bool,
             p: float, layer: int, sink, keys: Dict[str, str], need_dx: bool = True, g_in: Optional[Tensor] = None,
             emit=None):
-    x2d, h, mean, rstd, f = saved
+    x2d, h, mean, rstd, f, bits = saved
     if w2 is None:
         part, stride, n = sink.vector(keys["b1"], w1.shape[0])
         df = ops.dropout_bwd_cast(dy, run.act, 0.0, None, 0, relu_mask=f, colsum_part=part, part_stride=stride, n_partials=n)
@@ -246,7 +250,10 @@ def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2:
             g = ops.dropout_bwd_cast(dy, run.act, run.p(p), run.rng, site_ffn(layer), colsum_part=part, part_stride=stride,
                                      n_partials=n)
         weight_grad(sink, keys["w2"], g, f, w2.shape[0], w2.shape[1])
-        df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], relu_mask=f)
+        if bits is not None:
+            df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], sign_bits=bits)
+        else:
+            df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], relu_mask=f)
         part, stride, n = sink.vector(keys["b1"], w1.shape[0])
         ops.colsum(df, part, stride, n)
     weight_grad(sink, keys["w1"], df, h, w1.shape[0], w1.shape[1])

@@ -101,10 +101,16 @@ int dg_layernorm_bwd_fused(const float* dy, const float* x, const float* gamma, 
  * src/model_component.py:392-393,404 (packed q/k/v), :454 (proj), :321-323 (FFN),
  * src/model.py:599 (lm_head) -- and, with B = W^T, every Linear's dX = dY . W.
  * Epilogue, in this order (each optional):
- *    v = acc + bias[n];  v = max(v,0) if relu;  v = 0 where relu_mask[m,n] <= 0;
+ *    v = acc + bias[n];  v = max(v,0) if relu;  v = 0 where relu_mask[m,n] <= 0 (or its sign_bits bit is clear);
  *    v = dropout(v; p, site);  v += residual[m,n];  C[m,n] = (out_dtype) v
  * in_dtype: type of A, B and relu_mask.  K and lda/ldb must be multiples of 16 bytes' worth of
- * elements (8 bf16 / 4 f32) and A, B 16-byte aligned. */
+ * elements (8 bf16 / 4 f32) and A, B 16-byte aligned.
+ * sign_bits_out / sign_bits: the ReLU mask as one BIT per element (C[m,n] > 0).  The forward Linear+ReLU of
+ * FeedForward (ref: src/model_component.py:321-322) emits it next to C; the dX GEMM of the second Linear consumes it
+ * instead of re-reading the 16x larger activation.  The buffer (dg_gemm_nt_sign_bits_bytes(M, N) bytes) is OPAQUE: bits
+ * are stored in the order the kernel's lanes own the output tile, so it is only meaningful between a producing and a
+ * consuming dg_gemm_nt call with the same M and N.  Supported when dg_gemm_nt_sign_bits_supported(args) is non-zero
+ * (bf16 operands, N % 8 == 0, K % 64 == 0, K >= 128); DG_ERR_ARG otherwise. */
 typedef struct dg_gemm_nt_args {
     const void* A; int64_t lda;
     const void* B; int64_t ldb;
@@ -118,8 +124,13 @@ typedef struct dg_gemm_nt_args {
     float dropout_p;
     const uint32_t* rng_state;
     uint32_t site;
+    uint8_t* sign_bits_out;        /* nullable */
+    const uint8_t* sign_bits;      /* nullable; excludes relu_mask */
+    int64_t sign_bits_bytes;       /* size of either buffer, >= dg_gemm_nt_sign_bits_bytes(M, N) */
 } dg_gemm_nt_args;
 int dg_gemm_nt(const dg_gemm_nt_args* args, void* stream);
+int dg_gemm_nt_sign_bits_supported(const dg_gemm_nt_args* args);
+int64_t dg_gemm_nt_sign_bits_bytes(int M, int N);
 
 /* GEMM "TN": weight gradients, dW[P,Q] = sum_r A[r,P] * B[r,Q]  (A = dY [R,P], B = X [R,Q]).
  * The contraction over the R = B*T rows is split n_splits ways across workgroups; split s

@@ -69,6 +69,20 @@ def test_gemm_nt_epilogue(dev, dtype, M, N, K):
     assert rel(out, ref) < 2e-6
     out = ops.gemm_nt(A.to(dev), B.to(dev), dtype, relu_mask=mask.to(dev), bias=bias.to(dev))
     assert rel(out, acc * (mask.double() > 0)) < tol
+    # the same mask as one bit per element: emitted by the Linear+ReLU GEMM, consumed by the dX GEMM
+    if ops.gemm_nt_sign_bits_supported(dtype, N, K):
+        bits = ops.new_sign_bits(M, N, dev)
+        out = ops.gemm_nt(A.to(dev), B.to(dev), dtype, bias=bias.to(dev), relu=True, sign_bits_out=bits)
+        assert rel(out, acc.clamp_min(0)) < tol
+        pos = (out.float().cpu() > 0)
+        out2 = ops.gemm_nt(A.to(dev), B.to(dev), dtype, bias=bias.to(dev), sign_bits=bits)
+        assert rel(out2, acc * pos.double()) < tol
+        out3 = ops.gemm_nt(A.to(dev), B.to(dev), torch.float32, sign_bits=bits)
+        assert rel(out3, (A.double() @ B.double().T) * pos.double()) < 2e-6
+    else:
+        assert dtype == torch.float32 or N % 8
+        with pytest.raises(RuntimeError):
+            ops.gemm_nt(A.to(dev), B.to(dev), dtype, sign_bits=torch.zeros(M * N, dtype=torch.uint8, device=dev))
     # bias + dropout + residual, fp32 out; mask recomputed on the host from the same hash
     seed, step, site, p = 1234, 5, 9, 0.25
     rng = ops.new_rng_state(seed, dev, step)
