@@ -209,11 +209,11 @@ def kernel_roofline(eng, offsets, peak_tflops):
             sym = "gemm_tn_f32_kernel"
         calls.append((sym, 2.0 * A.shape[0] * P * Q, lambda: real_tn(A, Bm, out_part, split_stride, n_splits, P, Q, ldo)))
 
-    def tng(problems):
+    def tng(problems, workspace=None):
         problems = list(problems)
-        real_tng(problems)
+        real_tng(problems, workspace)
         fl = sum(2.0 * A.shape[0] * P * Q for A, _, _, P, Q in problems)
-        calls.append(("gemm_tn_grouped_kernel", fl, lambda: real_tng(problems)))
+        calls.append(("gemm_tn_grouped_kernel", fl, lambda: real_tng(problems, workspace)))
 
     eng.set_offsets(offsets)
     ops.gemm_nt, ops.gemm_tn, ops.gemm_tn_grouped = nt, tn, tng

@@ -66,7 +66,8 @@ SIGNATURES = {
     "dg_gemm_nt_sign_bits_supported": [C.POINTER(GemmNtArgs)],
     "dg_gemm_nt_sign_bits_bytes": [_i, _i],
     "dg_gemm_tn": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp],
-    "dg_gemm_tn_grouped": [C.POINTER(TnProblem), _i, _i, _vp],
+    "dg_gemm_tn_grouped": [C.POINTER(TnProblem), _i, _i, _vp, _i64, _vp],
+    "dg_gemm_tn_grouped_workspace_bytes": [C.POINTER(TnProblem), _i],
     "dg_reduce_partials": [_vp, _i64, _i, _vp, _i64, _vp],
     "dg_colsum": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _vp],
     "dg_dropout_bwd_cast": [_vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp, _u32, _vp, _i64, _vp, _i64, _i, _vp],
@@ -97,6 +98,7 @@ def _load() -> C.CDLL:
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.dg_gemm_nt_sign_bits_bytes.restype = C.c_int64
+    lib.dg_gemm_tn_grouped_workspace_bytes.restype = C.c_int64
     lib.dg_error_string.argtypes = [C.c_int]
     lib.dg_error_string.restype = C.c_char_p
     v = lib.dg_version()

@@ -1694,7 +1694,8 @@ struct TnProblem {
     int64_t lda_b, ldb_b, ldo;
     int P, Q, R, tiles_q, tile_begin, pad;
 };
-struct TnGroup { int n, total_tiles; TnProblem pr[TN_MAX_GROUP]; };
+// ws (256-row-tile kernel only): split-K workspace, [total_tiles][8 waves][16 KB] fp32 partials then [total_tiles][8] flags
+struct TnGroup { int n, total_tiles; int splits, tiles_pad; char* ws; TnProblem pr[TN_MAX_GROUP]; };
 
 __global__ __launch_bounds__(768) void gemm_tn_grouped_kernel(TnGroup gp) {
     __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE];
@@ -1839,6 +1840,206 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped_kernel(TnGroup gp) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 x 128 output tiles for the grouped dW GEMM: 8 MFMA waves in 4 x 2, wave tile 64 x 64.  The dW K step is bound by
+// the transposed LDS reads (ds_read_b64_tr_b16: ~5 cycles each; tools/fillbench.hip), and a 64 x 64 wave tile needs
+// 32 of them per 32 MFMAs where the 32 x 64 tile of gemm_tn_grouped_kernel needs 24 per 16.  Stage = three
+// [64 r][128 cols] images (A columns 0..127, A columns 128..255, B) = 48 KB, three stages.
+#define TN2_STAGE 49152
+#define TN2_NST 3
+__global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
+    __shared__ __attribute__((aligned(16))) char lds[TN2_NST * TN2_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x;
+    // Work items: (tile, K half).  With splits == 2 every tile is cut into two K halves handled by different workgroups one
+    // round apart (all first halves come first in the item order): 381 tiles on 256 CUs then cost 3 rounds of 128 K steps
+    // instead of 2 rounds of 256.  The first half publishes its accumulators (per wave: 16 KB + a flag, agent-scope
+    // release); the second half adds them after its own K range -- first + second, a fixed order -- and stores.
+    const int n_items = gp.splits * gp.tiles_pad;
+    const int my_items = (n_items - (int)blockIdx.x + G - 1) / G;
+    struct Item { int pi, p0, q0, ka, kb, tile, half; };
+    auto item = [&](int ii, Item& x) -> bool {                   // false: padding item (nothing to do)
+        const int it = (int)blockIdx.x + ii * G;
+        x.half = it / gp.tiles_pad;
+        const int tl = it - x.half * gp.tiles_pad;
+        if (tl >= gp.total_tiles) return false;
+        x.tile = dg_xcd_remap(tl, gp.total_tiles);
+        int pi = 0;
+        for (int i = 1; i < gp.n; ++i)
+            if (x.tile >= gp.pr[i].tile_begin) pi = i;
+        const int local = x.tile - gp.pr[pi].tile_begin;
+        x.pi = pi;
+        x.p0 = (local / gp.pr[pi].tiles_q) * 256; x.q0 = (local % gp.pr[pi].tiles_q) * 128;
+        const int nk = gp.pr[pi].R / 64, mid = gp.splits == 2 ? nk / 2 : nk;
+        x.ka = x.half ? mid : 0; x.kb = x.half ? nk : mid;
+        return true;
+    };
+    int total = 0;
+    for (int ii = 0; ii < my_items; ++ii) {
+        Item x;
+        if (item(ii, x)) total += x.kb - x.ka;
+    }
+    if (total == 0) return;
+
+    if (wave >= 8) {
+        // ---- loader role: 48 pieces of 1 KB (4 rows x 256 B) per stage, 12 per wave: pieces 0-15 -> image A0, 16-31 -> A1, 32-47 -> B
+        const int lw = wave - 8;
+        const int prow = lane >> 4, slot = lane & 15;
+        const char* src[12];
+        int64_t step[12];
+        int nk_iss = 1, iss_item = -1;
+        auto set_src = [&]() {                                    // advance to the next real item
+            Item x;
+            do { if (++iss_item >= my_items) return; } while (!item(iss_item, x));
+            const TnProblem& pr = gp.pr[x.pi];
+            nk_iss = x.kb - x.ka;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int pc = 12 * lw + i, img = pc >> 4, q = pc & 15;
+                const int row = x.ka * 64 + 4 * q + prow;
+                const int chunk = slot ^ ((prow << 2) | (q & 3));
+                const bool isB = img == 2;
+                const int64_t ld_b = isB ? pr.ldb_b : pr.lda_b;
+                int c = (isB ? x.q0 : x.p0 + img * 128) + chunk * 8;
+                if (c + 8 > ld_b / 2) c = 0;                      // past the leading dimension: clamp
+                src[i] = (isB ? pr.B : pr.A) + (int64_t)row * ld_b + (int64_t)c * 2;
+                step[i] = 64 * ld_b;
+            }
+        };
+        int iss_kt = 0, iss_buf = 0;
+        auto issue = [&]() {
+            char* base = lds + iss_buf * TN2_STAGE + (12 * lw) * 1024;
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + (int64_t)iss_kt * step[i]), (lptr_t)(base + i * 1024), 16, 0, 0);
+            if (++iss_buf == TN2_NST) iss_buf = 0;
+            if (++iss_kt == nk_iss) { iss_kt = 0; set_src(); }
+        };
+        // All three buffers stay busy: the consumers read BOTH K halves of stage g right after barrier g-1, so its buffer is
+        // free again at barrier g and stage g+3 is issued there -- two K steps before it is needed.
+        set_src();
+        const int npre = total < TN2_NST ? total : TN2_NST;
+        for (int g = 0; g < npre; ++g) issue();
+        if (npre >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (npre == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // stage 0 published
+        for (int g = 0; g + 1 < total; ++g) {
+            int issued = g + TN2_NST; if (issued > total) issued = total;
+            if (issued - (g + 2) >= 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // stage g+1 landed, g+2 may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                          // publishes stage g+1; stage g's buffer is free
+            if (g + TN2_NST < total) issue();
+        }
+        return;
+    }
+
+    // ---- MFMA role
+    const int wp = wave >> 1, wq = wave & 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    const int aimg = (wp >> 1) * 16384, acol = (wp & 1) * 64;
+    auto read_frags = [&](u32x4 (&fa)[4], u32x4 (&fb)[4], const char* buf, int ks) {
+        const int r0 = ks * 32 + fg * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = tn_frag_bf16(buf + aimg, r0, acol + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = tn_frag_bf16(buf + 32768, r0, wq * 64 + j * 16, lane);
+    };
+    auto mma_all = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
+    };
+    Item cx;
+    int cur_item = -1;
+    auto next_item = [&]() {
+        do { if (++cur_item >= my_items) return; } while (!item(cur_item, cx));
+    };
+    next_item();
+    auto store_tile = [&]() {
+        const TnProblem& pr = gp.pr[cx.pi];
+        if (gp.splits == 2) {
+            float* part = (float*)(gp.ws + ((size_t)cx.tile * 8 + wave) * 16384);
+            unsigned* flag = (unsigned*)(gp.ws + (size_t)gp.total_tiles * 8 * 16384) + cx.tile * 8 + wave;
+            if (cx.half == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            __hip_atomic_store(part + ((i * 4 + j) * 4 + e) * 64 + lane, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                // The partial sums and the flag are agent-scope atomic accesses (performed at the level all XCDs share), so
+                // ordering them needs only "my stores have been acknowledged": a workgroup-scope fence.  An agent-scope
+                // release / acquire pair would write back and invalidate the whole L2 of the XCD on every hand-over, which
+                // made this kernel 2x slower than not splitting at all.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[i][j][e] += __hip_atomic_load(part + ((i * 4 + j) * 4 + e) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        float* out = pr.out;
+        const bool vec = (pr.ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = cx.p0 + wp * 64 + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = cx.q0 + wq * 64 + j * 16 + 4 * fg;
+                if (row < pr.P) {
+                    float* op = out + (int64_t)row * pr.ldo + col;
+                    if (vec && col + 3 < pr.Q) *(f32x4*)op = acc[i][j];
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (col + e < pr.Q) op[e] = acc[i][j][e];
+                    }
+                }
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
+    __builtin_amdgcn_s_barrier();                                  // stage 0 published by the loaders
+    int kt = 0, buf_i = 0;
+    for (int g = 0; g < total; ++g) {
+        const char* buf = lds + buf_i * TN2_STAGE;
+        read_frags(fa0, fb0, buf, 0);
+        read_frags(fa1, fb1, buf, 1);
+        mma_all(fa0, fb0);
+        mma_all(fa1, fb1);
+        if (++buf_i == TN2_NST) buf_i = 0;
+        if (++kt == cx.kb - cx.ka) {
+            store_tile();
+            kt = 0;
+            next_item();
+        }
+        if (g + 1 < total) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every read of stage g has returned: the loaders refill its buffer
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
 // ---- f32: [32 r][128 cols] tiles with 144-float row pitch (pad 16 floats: rows r, r+1 of one
 //      ds_read_b32 half-wave land on different banks)
 #define TNF_PITCH 144
@@ -1963,7 +2164,28 @@ extern "C" int dg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
     return DG_OK;
 }
 
-extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtype, void* stream) {
+static int tn_tile_p() {
+    static const int v = [] { const char* e = getenv("DG_TN_TILE"); return (e && atoi(e) == 128) ? 128 : 256; }();   // output tile rows
+    return v;
+}
+static int64_t tn_group_tiles(const dg_tn_problem* problems, int n) {
+    int64_t tiles = 0;
+    for (int i = 0; i < n; ++i) tiles += (int64_t)((problems[i].P + tn_tile_p() - 1) / tn_tile_p()) * ((problems[i].Q + 127) / 128);
+    return tiles;
+}
+// split-K workspace for the largest launch group of the call: per 256 x 128 tile 8 x 16 KB of wave partials + 8 flags
+extern "C" int64_t dg_gemm_tn_grouped_workspace_bytes(const dg_tn_problem* problems, int n) {
+    if (!problems || n <= 0 || tn_tile_p() != 256) return 0;
+    int64_t most = 0;
+    for (int base = 0; base < n; base += TN_MAX_GROUP) {
+        const int64_t t = tn_group_tiles(problems + base, n - base < TN_MAX_GROUP ? n - base : TN_MAX_GROUP);
+        if (t > most) most = t;
+    }
+    return most * (8 * 16384 + 8 * 4);
+}
+
+extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtype, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
     if (!problems || n <= 0) return DG_ERR_ARG;
     if (dtype != DG_BF16) return DG_ERR_DTYPE;
     for (int i = 0; i < n; ++i) {
@@ -1973,11 +2195,14 @@ extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtyp
         if (q.lda < q.P || q.ldb < q.Q || q.ldo < q.Q) return DG_ERR_ARG;
         if (((q.P + 7) / 8) * 8 > q.lda || ((q.Q + 7) / 8) * 8 > q.ldb) return DG_ERR_ARG;
     }
+    if (workspace && (!dg_aligned16(workspace) || workspace_bytes < dg_gemm_tn_grouped_workspace_bytes(problems, n))) return DG_ERR_ARG;
+    static const int split_mode = [] { const char* e = getenv("DG_TN_SPLIT"); return e ? atoi(e) : 1; }();   // 0 = never split (A/B runs)
     hipStream_t s = (hipStream_t)stream;
+    const int tile_p = tn_tile_p();
     for (int base = 0; base < n; base += TN_MAX_GROUP) {
         TnGroup gp;
         gp.n = n - base < TN_MAX_GROUP ? n - base : TN_MAX_GROUP;
-        int tiles = 0;
+        int tiles = 0, nk_min = 1 << 30, nk_max = 0;
         for (int i = 0; i < gp.n; ++i) {
             const dg_tn_problem& q = problems[base + i];
             TnProblem& t = gp.pr[i];
@@ -1987,11 +2212,26 @@ extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtyp
             t.tiles_q = (q.Q + 127) / 128;
             t.tile_begin = tiles;
             t.pad = 0;
-            tiles += ((q.P + 127) / 128) * t.tiles_q;
+            tiles += ((q.P + tile_p - 1) / tile_p) * t.tiles_q;
+            const int nk = q.R / 64;
+            if (nk < nk_min) nk_min = nk;
+            if (nk > nk_max) nk_max = nk;
         }
         gp.total_tiles = tiles;
-        const int grid = tiles < dg_num_cus() ? tiles : dg_num_cus();
-        hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(grid), dim3(768), 0, s, gp);
+        gp.tiles_pad = (tiles + 7) / 8 * 8;
+        gp.splits = 1;
+        gp.ws = nullptr;
+        const int ncu = dg_num_cus();
+        if (tile_p == 256 && workspace && split_mode && nk_min >= 2) {
+            // two K halves per tile when that shortens the schedule: rounds x steps per round
+            const int64_t whole = (int64_t)((tiles + ncu - 1) / ncu) * nk_max;
+            const int64_t halves = (int64_t)((2 * gp.tiles_pad + ncu - 1) / ncu) * ((nk_max + 1) / 2);
+            if (halves < whole) { gp.splits = 2; gp.ws = (char*)workspace; }
+        }
+        const int items = gp.splits * gp.tiles_pad;
+        const int grid = items < ncu ? items : ncu;
+        if (tile_p == 256) hipLaunchKernelGGL(gemm_tn_grouped256_kernel, dim3(grid), dim3(768), 0, s, gp);
+        else hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(tiles < ncu ? tiles : ncu), dim3(768), 0, s, gp);
         DG_LAUNCH_CHECK();
     }
     return DG_OK;

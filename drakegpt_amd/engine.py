@@ -82,7 +82,9 @@ class FlatSink:
 
     def flush(self):
         if self.deferred:
-            ops.gemm_tn_grouped(self.deferred)
+            if self.e.tn_workspace is None:            # first step: sized for this problem set, zero-filled once
+                self.e.tn_workspace = ops.gemm_tn_grouped_workspace(self.deferred, self.e.dev)
+            ops.gemm_tn_grouped(self.deferred, self.e.tn_workspace)
             self.deferred = []
 
     def matrix(self, key, P, Q):
@@ -200,6 +202,7 @@ class TrainEngine:
         self.gflat = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
         self.m_ = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
         self.v_ = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
+        self.tn_workspace = None
         self.slabs = None if self.grouped_dw else torch.zeros((self.S, self.layA.size), dtype=torch.float32, device=dev)
         self.vparts = torch.zeros((self.G, self.layB.size), dtype=torch.float32, device=dev)
         NH, H = self.NH, self.H

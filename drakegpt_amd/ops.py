@@ -225,9 +225,7 @@ def gemm_tn(A: Tensor, Bm: Tensor, out_part: Tensor, split_stride: int, n_splits
                          A.shape[0], P, Q, dt_code(A.dtype), _stream()), "dg_gemm_tn")
 
 
-def gemm_tn_grouped(problems) -> None:
-    """every dW of a backward pass in one launch: problems = [(A [R,>=P], B [R,>=Q], out [P,Q] fp32, P, Q), ...];
-    out_i = A_i[:, :P]^T B_i[:, :Q] over all R rows (bf16 operands, R % 64 == 0).  The caller keeps the operands alive."""
+def _tn_problem_array(problems):
     from ._lib import TnProblem
     arr = (TnProblem * len(problems))()
     for t, (A, Bm, out, P, Q) in zip(arr, problems):
@@ -238,7 +236,24 @@ def gemm_tn_grouped(problems) -> None:
             raise RuntimeError("gemm_tn_grouped: operand mismatch")
         t.A, t.lda, t.B, t.ldb, t.out, t.ldo = _p(A), _ld(A), _p(Bm), _ld(Bm), _p(out), Q
         t.R, t.P, t.Q, t.reserved = A.shape[0], P, Q, 0
-    check(lib.dg_gemm_tn_grouped(arr, len(problems), dt_code(torch.bfloat16), _stream()), "dg_gemm_tn_grouped")
+    return arr
+
+
+def gemm_tn_grouped_workspace(problems, device) -> Tensor:
+    """zero-filled split-K workspace for gemm_tn_grouped on these problems (allocate once, pass to every call)"""
+    arr = _tn_problem_array(problems)
+    return torch.zeros(max(16, int(lib.dg_gemm_tn_grouped_workspace_bytes(arr, len(problems)))), dtype=torch.uint8, device=device)
+
+
+def gemm_tn_grouped(problems, workspace: Optional[Tensor] = None) -> None:
+    """every dW of a backward pass in one launch: problems = [(A [R,>=P], B [R,>=Q], out [P,Q] fp32, P, Q), ...];
+    out_i = A_i[:, :P]^T B_i[:, :Q] over all R rows (bf16 operands, R % 64 == 0).  The caller keeps the operands alive.
+    `workspace` (gemm_tn_grouped_workspace) lets the kernel split the contraction of every tile in two."""
+    arr = _tn_problem_array(problems)
+    if workspace is not None:
+        _chk(workspace, "workspace", torch.uint8)
+    check(lib.dg_gemm_tn_grouped(arr, len(problems), dt_code(torch.bfloat16), _p(workspace) if workspace is not None else None,
+                                 workspace.numel() if workspace is not None else 0, _stream()), "dg_gemm_tn_grouped")
 
 
 def reduce_partials(part: Tensor, stride: int, n_partials: int, out: Tensor, n: int) -> None:

@@ -153,7 +153,12 @@ typedef struct dg_tn_problem {
     float* out; int64_t ldo;        /* dW [P,Q] fp32, overwritten */
     int R, P, Q, reserved;
 } dg_tn_problem;
-int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtype, void* stream);
+int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
+/* Optional workspace (device memory of dg_gemm_tn_grouped_workspace_bytes(problems, n) bytes, zero-filled ONCE by the
+ * caller and then left to the library between calls on one stream): lets the kernel cut every tile's contraction into
+ * two halves run by different workgroups when that shortens the schedule (381 tiles on 256 CUs: 3 rounds of half
+ * tiles instead of 2 rounds of whole ones).  The halves are summed first + second, a fixed order.  NULL = no split. */
+int64_t dg_gemm_tn_grouped_workspace_bytes(const dg_tn_problem* problems, int n);
 
 /* out[i] = sum_{g < n_partials} partials[g*stride + i], i < n.  Deterministic order. */
 int dg_reduce_partials(const float* partials, int64_t stride, int n_partials,

@@ -109,12 +109,14 @@ def test_gemm_tn(dev, dtype, R, P, Q, S):
     assert rel(out, ref) < 3e-6, rel(out, ref)
 
 
-def test_gemm_tn_grouped(dev):
+@pytest.mark.parametrize("with_short", [True, False])
+def test_gemm_tn_grouped(dev, with_short):
     """one launch for many dW problems (different shapes and contraction lengths, ragged P/Q, column-sliced operands);
-    more tiles than CUs so workgroups walk several tiles of different problems with one stage pipeline."""
+    more tiles than CUs so workgroups walk several tiles of different problems with one stage pipeline.  Without the
+    one-K-step problem the workspace run splits every tile into two K halves chained through flags."""
     ops = _ops()
     g = torch.Generator().manual_seed(11)
-    shapes = [(1024, 384, 384), (1024, 1152, 384), (1024, 384, 1536), (1024, 1536, 384), (1024, 80, 384), (64, 200, 72),
+    shapes = [(1024, 384, 384), (1024, 1152, 384), (1024, 384, 1536), (1024, 1536, 384), (1024, 80, 384), (64 if with_short else 320, 200, 72),
               (2048, 1536, 768), (512, 128, 128), (192, 264, 520)] * 2
     shapes += [(256, 2048, 2048)]                       # 256 tiles on its own
     probs, refs, outs = [], [], []
@@ -129,11 +131,21 @@ def test_gemm_tn_grouped(dev):
         out = torch.full((P * Q,), float("nan"), device=dev)
         outs.append(out)
         probs.append((A.to(dev)[:, :P] if lda != P else A.to(dev), B.to(dev)[:, :Q] if ldb != Q else B.to(dev), out, P, Q))
-    assert sum(((P + 127) // 128) * ((Q + 127) // 128) for _, P, Q in shapes) > 256
-    ops.gemm_tn_grouped(probs)
-    torch.cuda.synchronize()
-    for out, ref, (R, P, Q) in zip(outs, refs, shapes):
-        assert rel(out.view(P, Q), ref) < 3e-6, (R, P, Q, rel(out.view(P, Q), ref))
+    assert sum(((P + 255) // 256) * ((Q + 127) // 128) for _, P, Q in shapes) > 256
+    ws = ops.gemm_tn_grouped_workspace(probs, dev)
+    first = None
+    for workspace in (None, ws, ws):                    # whole tiles, then K halves twice (the flags must reset themselves)
+        for out in outs:
+            out.fill_(float("nan"))
+        ops.gemm_tn_grouped(probs, workspace)
+        torch.cuda.synchronize()
+        for out, ref, (R, P, Q) in zip(outs, refs, shapes):
+            assert rel(out.view(P, Q), ref) < 3e-6, (workspace is not None, R, P, Q, rel(out.view(P, Q), ref))
+        if workspace is not None:
+            if first is None:
+                first = [o.clone() for o in outs]
+            else:
+                assert all(torch.equal(a, b) for a, b in zip(first, outs))     # run-to-run identical
     with pytest.raises(RuntimeError):                   # contraction length must be a multiple of 64
         ops.gemm_tn_grouped([(torch.zeros(100, 64, dtype=torch.bfloat16, device=dev), torch.zeros(100, 64, dtype=torch.bfloat16, device=dev),
                               torch.zeros(64 * 64, device=dev), 64, 64)])
