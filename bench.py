@@ -213,7 +213,8 @@ def kernel_roofline(eng, offsets, peak_tflops):
         problems = list(problems)
         real_tng(problems, workspace)
         fl = sum(2.0 * A.shape[0] * P * Q for A, _, _, P, Q in problems)
-        calls.append(("gemm_tn_grouped_kernel", fl, lambda: real_tng(problems, workspace)))
+        sym = "gemm_tn_grouped_kernel" if os.environ.get("DG_TN_TILE") == "128" else "gemm_tn_grouped256_kernel"
+        calls.append((sym, fl, lambda: real_tng(problems, workspace)))
 
     eng.set_offsets(offsets)
     ops.gemm_nt, ops.gemm_tn, ops.gemm_tn_grouped = nt, tn, tng

@@ -1309,7 +1309,8 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
         else hipLaunchKernelGGL((gemm_nt_pp_kernel<float>), pgrid, dim3(384), 0, s, p);
     } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 0) {
         dim3 pgrid(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
-        const bool pf = a->sign_bits != nullptr && p.vec_ok && (!a->bias || dg_aligned16(a->bias)) &&
+        static const int pf_mode = [] { const char* e = getenv("DG_GEMM_PF"); return e ? atoi(e) : 1; }();   // 0 = load the mask bits inside the epilogue (A/B runs)
+        const bool pf = pf_mode && a->sign_bits != nullptr && p.vec_ok && (!a->bias || dg_aligned16(a->bias)) &&
                         (a->ldc * (a->out_dtype == DG_BF16 ? 2 : 4)) % 16 == 0 && dg_aligned16(a->C);
         const bool wide = dg_nt_wide(a->N);                       // 128 x 192 tiles
         if (wide) {

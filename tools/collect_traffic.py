@@ -32,12 +32,18 @@ def per_kernel(d, counter):
 
 
 def short(name):
-    m = re.match(r"_Z\d+(\w+?)I(DF16b|f)(DF16b|f)?Ev", name)        # hipcc leaves __bf16 template args mangled
+    """kernel symbol as bench.py spells it: gemm_nt_ws_kernel<bf16,false,6>, gemm_tn_grouped256_kernel, ..."""
+    m = re.match(r"_Z\d+(\w+?)I((?:DF16b|f|Lb[01]E|Li\d+E)+)Ev", name)      # hipcc leaves __bf16 template args mangled
     if m:
-        t = {"DF16b": "bf16", "f": "float"}
-        return f"{m.group(1)}<{','.join(t[g] for g in m.groups()[1:] if g)}>"
+        out = []
+        for tok in re.findall(r"DF16b|f|Lb[01]E|Li\d+E", m.group(2)):
+            if tok == "DF16b": out.append("bf16")
+            elif tok == "f": out.append("float")
+            elif tok.startswith("Lb"): out.append("true" if tok[2] == "1" else "false")
+            else: out.append(tok[2:-1])
+        return f"{m.group(1)}<{','.join(out)}>"
     name = re.sub(r"\(.*", "", name)
-    name = name.replace("void ", "")
+    name = name.replace("void ", "").replace(", ", ",")
     return name.strip()
 
 
