@@ -60,8 +60,8 @@ SIGNATURES = {
     "dg_embed_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "dg_embed_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "dg_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp],
-    "dg_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
-    "dg_layernorm_bwd_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _vp, _u32, _vp, _vp],
+    "dg_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "dg_layernorm_bwd_fused": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _vp, _u32, _vp, _vp],
     "dg_gemm_nt": [C.POINTER(GemmNtArgs), _vp],
     "dg_gemm_nt_sign_bits_supported": [C.POINTER(GemmNtArgs)],
     "dg_gemm_nt_sign_bits_bytes": [_i, _i],

@@ -119,8 +119,8 @@ extern "C" int dg_layernorm_fwd(const float* x, const float* gamma, const float*
 struct LnFuse {
     void* g; float* gbias_part; float inv_keep; uint32_t thr; int drop; const uint32_t* rng; uint32_t site;
 };
-template <bool VEC, int LN_MAXV, int NTHREADS, int FUSE_G /*0 none, 1 bf16, 2 f32*/>
-__global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const float* __restrict__ dy, const float* __restrict__ x,
+template <typename TD /* dy: float, or bf16 on the vector path */, bool VEC, int LN_MAXV, int NTHREADS, int FUSE_G /*0 none, 1 bf16, 2 f32*/>
+__global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* __restrict__ dy, const float* __restrict__ x,
                               const float* __restrict__ gamma, const float* __restrict__ mean,
                               const float* __restrict__ rstd, const float* __restrict__ dresid,
                               float* __restrict__ dx, float* __restrict__ dgamma_part,
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const float
         if (FUSE_G && fz.drop) fkey = dg_site_key_dev(fz.rng, fz.site);
         for (int row = m_begin + w; row < m_end; row += NW) {
             const float mu = mean[row], rs = rstd[row];
-            const f32x4* dyr = (const f32x4*)(dy + (int64_t)row * C);
+            typedef TD TD4 __attribute__((ext_vector_type(4)));
+            const TD4* dyr = (const TD4*)(dy + (int64_t)row * C);
             const f32x4* xr = (const f32x4*)(x + (int64_t)row * C);
             f32x4 gv[LN_MAXV], xh[LN_MAXV];
             float s1 = 0.f, s2 = 0.f;
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const float
             for (int k = 0; k < LN_MAXV; ++k) {
                 int i = lane + k * 64;
                 if (i < nv) {
-                    f32x4 d = dyr[i], xx = xr[i];
+                    const TD4 dt = dyr[i];
+                    const f32x4 d = {(float)dt[0], (float)dt[1], (float)dt[2], (float)dt[3]}, xx = xr[i];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float h = (xx[j] - mu) * rs;
@@ -226,18 +228,18 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const float
         for (int c = lane; c < C; c += 64) { lg[w * C + c] = 0.f; lb[w * C + c] = 0.f; }
         for (int row = m_begin + w; row < m_end; row += NW) {
             const float mu = mean[row], rs = rstd[row];
-            const float* dyr = dy + (int64_t)row * C;
+            const TD* dyr = dy + (int64_t)row * C;
             const float* xr = x + (int64_t)row * C;
             float s1 = 0.f, s2 = 0.f;
             for (int c = lane; c < C; c += 64) {
-                float h = (xr[c] - mu) * rs, gg = dyr[c] * gamma[c];
+                float h = (xr[c] - mu) * rs, gg = (float)dyr[c] * gamma[c];
                 s1 += gg; s2 += gg * h;
-                lg[w * C + c] += dyr[c] * h;
-                lb[w * C + c] += dyr[c];
+                lg[w * C + c] += (float)dyr[c] * h;
+                lb[w * C + c] += (float)dyr[c];
             }
             const float c1 = wave_sum(s1) * invC, c2 = wave_sum(s2) * invC;
             for (int c = lane; c < C; c += 64) {
-                float h = (xr[c] - mu) * rs, gg = dyr[c] * gamma[c];
+                float h = (xr[c] - mu) * rs, gg = (float)dyr[c] * gamma[c];
                 float o = rs * (gg - c1 - h * c2);
                 if (dresid) o += dresid[(int64_t)row * C + c];
                 dx[(int64_t)row * C + c] = o;
@@ -254,16 +256,18 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const float
     }
 }
 
-static int ln_bwd_launch(LnFuse fz, int fuse, const float* dy, const float* x, const float* gamma, const float* mean,
+static int ln_bwd_launch(LnFuse fz, int fuse, const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                          const float* rstd, const float* dresid, float* dx,
                          float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
                          int M, int C, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma_part || !dbeta_part) return DG_ERR_ARG;
     if (M <= 0 || C <= 0 || n_partials <= 0 || part_stride < C) return DG_ERR_ARG;
+    if (dy_dtype != DG_F32 && dy_dtype != DG_BF16) return DG_ERR_DTYPE;
     bool vec = (C % 4 == 0) && (C <= 64 * 4 * LN_MAXV_CAP) && dg_aligned16(dy) && dg_aligned16(x) && dg_aligned16(gamma) &&
                dg_aligned16(dx) && (!dresid || dg_aligned16(dresid));
     const int nk = (C / 4 + 63) / 64;
     if (fuse && (!vec || nk > 4 || !fz.g || !fz.gbias_part || !dg_aligned16(fz.g))) return DG_ERR_ARG;
+    if (dy_dtype == DG_BF16 && !vec) return DG_ERR_ARG;         // bf16 gradients only on the vector path
     // more waves per workgroup = more rows in flight per partial (HBM-bound: needs the occupancy)
     int nthreads = C <= 512 ? 1024 : (C <= 1024 ? 512 : 256);
     size_t lds_bytes = (size_t)2 * (nthreads / 64) * C * sizeof(float);    // (the vector path uses half of it)
@@ -271,9 +275,10 @@ static int ln_bwd_launch(LnFuse fz, int fuse, const float* dy, const float* x, c
     dim3 grid(n_partials), block(nthreads);
     hipStream_t s = (hipStream_t)stream;
     if (lds_bytes > 64 * 1024) return DG_ERR_ARG;   // C <= 2048 on either path
-#define LAUNCH(V, K, NT, F) hipLaunchKernelGGL((ln_bwd_kernel<V, K, NT, F>), grid, block, lds_bytes, s, fz, dy, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part, part_stride, M, C, rows_per)
+#define LAUNCH_T(TD, V, K, NT, F) hipLaunchKernelGGL((ln_bwd_kernel<TD, V, K, NT, F>), grid, block, lds_bytes, s, fz, (const TD*)dy, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part, part_stride, M, C, rows_per)
+#define LAUNCH(V, K, NT, F) do { if (dy_dtype == DG_BF16) LAUNCH_T(bf16_t, true, K, NT, F); else LAUNCH_T(float, V, K, NT, F); } while (0)
     if (fuse == 0) {
-        if (!vec) { if (nthreads == 1024) LAUNCH(false, 1, 1024, 0); else if (nthreads == 512) LAUNCH(false, 1, 512, 0); else LAUNCH(false, 1, 256, 0); }
+        if (!vec) { if (nthreads == 1024) LAUNCH_T(float, false, 1, 1024, 0); else if (nthreads == 512) LAUNCH_T(float, false, 1, 512, 0); else LAUNCH_T(float, false, 1, 256, 0); }
         else if (nk <= 1) LAUNCH(true, 1, 1024, 0);
         else if (nk == 2) LAUNCH(true, 2, 1024, 0);
         else if (nk == 3) LAUNCH(true, 3, 512, 0);
@@ -286,20 +291,21 @@ static int ln_bwd_launch(LnFuse fz, int fuse, const float* dy, const float* x, c
         if (nk <= 1) LAUNCH(true, 1, 1024, 2); else if (nk == 2) LAUNCH(true, 2, 1024, 2);
         else if (nk == 3) LAUNCH(true, 3, 512, 2); else LAUNCH(true, 4, 512, 2);
     }
+#undef LAUNCH_T
 #undef LAUNCH
     DG_LAUNCH_CHECK();
     return DG_OK;
 }
 
-extern "C" int dg_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+extern "C" int dg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                                 const float* rstd, const float* dresid, float* dx,
                                 float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
                                 int M, int C, void* stream) {
     LnFuse fz = {};
-    return ln_bwd_launch(fz, 0, dy, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part, part_stride, n_partials, M, C, stream);
+    return ln_bwd_launch(fz, 0, dy, dy_dtype, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part, part_stride, n_partials, M, C, stream);
 }
 
-extern "C" int dg_layernorm_bwd_fused(const float* dy, const float* x, const float* gamma, const float* mean,
+extern "C" int dg_layernorm_bwd_fused(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                                       const float* rstd, const float* dresid, float* dx,
                                       float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
                                       int M, int C,
@@ -313,6 +319,6 @@ extern "C" int dg_layernorm_bwd_fused(const float* dy, const float* x, const flo
     fz.inv_keep = 1.f / (1.f - dropout_p);
     fz.thr = dg_drop_threshold(dropout_p);
     fz.rng = rng_state; fz.site = site;
-    return ln_bwd_launch(fz, g_dtype == DG_BF16 ? 1 : 2, dy, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part,
+    return ln_bwd_launch(fz, g_dtype == DG_BF16 ? 1 : 2, dy, dy_dtype, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part,
                          part_stride, n_partials, M, C, stream);
 }

@@ -122,7 +122,7 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, out_dtype: torch.dtype
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dresid: Optional[Tensor],
                   dgamma_part: Tensor, dbeta_part: Tensor, part_stride: int, n_partials: int,
                   dx: Optional[Tensor] = None) -> Tensor:
-    _chk(dy, "dy", torch.float32)
+    _chk(dy, "dy")                        # fp32, or bf16 straight from a dX GEMM
     _chk(x, "x", torch.float32)
     if dresid is not None:
         _chk(dresid, "dresid", torch.float32)
@@ -130,7 +130,7 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
     M = x.numel() // Cd
     if dx is None:
         dx = torch.empty_like(x)
-    check(lib.dg_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dresid), _p(dx), _p(dgamma_part), _p(dbeta_part),
+    check(lib.dg_layernorm_bwd(_p(dy), dt_code(dy.dtype), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dresid), _p(dx), _p(dgamma_part), _p(dbeta_part),
                                part_stride, n_partials, M, Cd, _stream()), "dg_layernorm_bwd")
     return dx
 
@@ -139,13 +139,13 @@ def layernorm_bwd_fused(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd
                         dgamma_part: Tensor, dbeta_part: Tensor, part_stride: int, n_partials: int,
                         g_dtype: torch.dtype, p: float, rng_state: Optional[Tensor], site: int, gbias_part: Tensor):
     """layernorm_bwd that also emits g = dropout_bwd(dx) in g_dtype and its column-sum partials; returns (dx, g)."""
-    _chk(dy, "dy", torch.float32)
+    _chk(dy, "dy")
     _chk(x, "x", torch.float32)
     Cd = x.shape[-1]
     M = x.numel() // Cd
     dx = torch.empty_like(x)
     g = torch.empty(x.shape, dtype=g_dtype, device=x.device)
-    check(lib.dg_layernorm_bwd_fused(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dresid), _p(dx), _p(dgamma_part),
+    check(lib.dg_layernorm_bwd_fused(_p(dy), dt_code(dy.dtype), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dresid), _p(dx), _p(dgamma_part),
                                      _p(dbeta_part), part_stride, n_partials, M, Cd, _p(g), dt_code(g_dtype), float(p),
                                      _p(rng_state) if p > 0.0 else None, site, _p(gbias_part), _stream()), "dg_layernorm_bwd_fused")
     return dx, g

@@ -149,6 +149,13 @@ def _as_act(run: Run, x2d: Tensor) -> Tensor:
     return x2d if x2d.dtype == run.act else ops.cast(x2d, run.act)
 
 
+def _dh_dtype(run: Run, ln_w: Tensor) -> torch.dtype:
+    """dtype of the gradient a dX GEMM hands to the LayerNorm backward: the activation type when the vector kernel can take it
+    (half the store of the GEMM and half the read of the LayerNorm backward; it is rounded once, like every other activation
+    gradient of the bf16 mode)"""
+    return run.act if (run.act == torch.bfloat16 and ln_w.numel() % 4 == 0 and ln_w.numel() <= 2048) else torch.float32
+
+
 def _ln_tail(run: Run, dh: Tensor, x2d: Tensor, ln_w: Tensor, mean, rstd, dresid, sink, keys, emit):
     """LayerNorm backward (+ residual-branch gradient).  With `emit = (p, site, bias_key, N)` the kernel also
     produces g = dropout_bwd(dx) for the sub-layer that runs next in backward, and that sub-layer's bias partials."""
@@ -206,7 +213,7 @@ def attn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], wqkv: Tensor, 
     if not need_dx:
         return None
     if ln_w is not None:
-        dh = ops.gemm_nt(dqkv, run.weights.bwd(wqkv), torch.float32, K=wqkv.shape[0])
+        dh = ops.gemm_nt(dqkv, run.weights.bwd(wqkv), _dh_dtype(run, ln_w), K=wqkv.shape[0])
         dx, g_next = _ln_tail(run, dh, x2d, ln_w, mean, rstd, dy if residual else None, sink, keys, emit)
         return (dx, g_next) if emit is not None else dx
     dx = ops.gemm_nt(dqkv, run.weights.bwd(wqkv), torch.float32, K=wqkv.shape[0], residual=dy if residual else None)
@@ -260,7 +267,7 @@ def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2:
     if not need_dx:
         return None
     if ln_w is not None:
-        dh = ops.gemm_nt(df, run.weights.bwd(w1), torch.float32, K=w1.shape[0])
+        dh = ops.gemm_nt(df, run.weights.bwd(w1), _dh_dtype(run, ln_w), K=w1.shape[0])
         dx, g_next = _ln_tail(run, dh, x2d, ln_w, mean, rstd, dy if residual else None, sink, keys, emit)
         return (dx, g_next) if emit is not None else dx
     dx = ops.gemm_nt(df, run.weights.bwd(w1), torch.float32, K=w1.shape[0], residual=dy if residual else None)

@@ -77,8 +77,9 @@ int dg_layernorm_fwd(const float* x, const float* gamma, const float* beta, void
                      float* mean, float* rstd, int M, int C, float eps, void* stream);
 /* dx = dresid (nullable, the residual branch's gradient) + LN'(dy).  dgamma/dbeta are emitted
  * as n_partials row-chunk partial sums: partial g at dgamma_part + g*part_stride (same for
- * dbeta_part); finish with dg_reduce_partials. */
-int dg_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+ * dbeta_part); finish with dg_reduce_partials.  dy_dtype: DG_F32, or DG_BF16 (C % 4 == 0 only) when dy comes
+ * straight out of a bf16-output dX GEMM. */
+int dg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                      const float* rstd, const float* dresid, float* dx,
                      float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
                      int M, int C, void* stream);
@@ -88,7 +89,7 @@ int dg_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
  * which runs next in backward would otherwise get from dg_dropout_bwd_cast(dx, site) -- one 38 MB pass and
  * one launch less per sub-layer.  Returns DG_ERR_ARG for shapes the fused kernel does not cover
  * (C % 4 != 0 or C > 1024): call dg_layernorm_bwd + dg_dropout_bwd_cast then. */
-int dg_layernorm_bwd_fused(const float* dy, const float* x, const float* gamma, const float* mean,
+int dg_layernorm_bwd_fused(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                            const float* rstd, const float* dresid, float* dx,
                            float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
                            int M, int C,

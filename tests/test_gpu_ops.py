@@ -206,6 +206,20 @@ def test_layernorm(dev, C, out_dtype):
     ops.reduce_partials(pg, C, G, dg, C)
     ops.reduce_partials(pb, C, G, db, C)
     assert rel(dg, wd.grad) < 2e-6 and rel(db, bd.grad) < 2e-6
+    if C % 4 == 0:
+        # dy handed over in bf16 (what a bf16-output dX GEMM produces): exact for the rounded dy
+        dyb = dy.bfloat16()
+        xd2 = x.double().requires_grad_(True)
+        wd2, bd2 = w.double().requires_grad_(True), b.double().requires_grad_(True)
+        torch.nn.functional.layer_norm(xd2, (C,), wd2, bd2, 1e-5).backward(dyb.double())
+        dx = ops.layernorm_bwd(dyb.to(dev), x.to(dev), w.to(dev), mean, rstd, dres.to(dev), pg, pb, C, G)
+        assert rel(dx, xd2.grad + dres.double()) < 2e-6
+        ops.reduce_partials(pg, C, G, dg, C)
+        ops.reduce_partials(pb, C, G, db, C)
+        assert rel(dg, wd2.grad) < 2e-6 and rel(db, bd2.grad) < 2e-6
+    else:
+        with pytest.raises(RuntimeError):
+            ops.layernorm_bwd(dy.bfloat16().to(dev), x.to(dev), w.to(dev), mean, rstd, dres.to(dev), pg, pb, C, G)
 
 
 def _attn_ref(qkv, B, T, NH, H, keep=None, p=0.0):
