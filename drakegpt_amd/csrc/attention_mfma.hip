@@ -67,13 +67,15 @@ __device__ __forceinline__ int off_row(int row, int ch) { return row * 128 + ((c
 // transposed-read image: a half-wave's 4 rows x 4 chunks land on 16 distinct 16-byte slots
 __device__ __forceinline__ int off_tr(int row, int ch) { return row * 128 + ((ch ^ (((row >> 1) & 1) << 2)) << 4); }
 
-// global [rows][HD] tile (row stride ld elements) -> 4 x 16 B per lane, rows >= T zero-filled
+// global [rows][HD] tile (row stride ld elements) -> 4 x 16 B per lane.  Rows >= T read row T-1 again (finite data):
+// every consumer masks them (causal mask / `ok` / bounded stores), and a clamped index keeps the load unconditional --
+// the predicated form cost one exec-mask branch per load (368 basic blocks in the dK/dV kernel).
 __device__ __forceinline__ void tile_load(u32x4 (&r)[4], const bf16_t* base, int64_t ld, int row0, int T, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = lane + 64 * i, row = c >> 3, ch = c & 7;
-        const int gr = row0 + row;
-        r[i] = (gr < T) ? *(const u32x4*)(base + (int64_t)gr * ld + ch * 8) : (u32x4){0u, 0u, 0u, 0u};
+        int gr = row0 + row; gr = gr < T ? gr : T - 1;
+        r[i] = *(const u32x4*)(base + (int64_t)gr * ld + ch * 8);
     }
 }
 template <bool TR>
@@ -107,10 +109,11 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s) {
 }
 // direct global fragment (rows on lanes): element j = M[row0 + lane&31][16*ks + 8*hh + j]
 __device__ __forceinline__ void frags_global(bf16x8 (&f)[4], const bf16_t* base, int64_t ld, int row0, int T, int lane) {
-    const int gr = row0 + (lane & 31), hh = lane >> 5;
+    int gr = row0 + (lane & 31); gr = gr < T ? gr : T - 1;     // clamped like tile_load
+    const int hh = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        u32x4 v = (gr < T) ? *(const u32x4*)(base + (int64_t)gr * ld + 16 * ks + 8 * hh) : (u32x4){0u, 0u, 0u, 0u};
+        u32x4 v = *(const u32x4*)(base + (int64_t)gr * ld + 16 * ks + 8 * hh);
         f[ks] = __builtin_bit_cast(bf16x8, v);
     }
 }
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
 // =============================================================================================
 // dQ: wave = 32 queries; per key tile: S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T
 #define WAVE_LDS_DQ 12288
+template <bool DROP>      // dropout on the probabilities (compile-time: no per-element uniform branch)
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
     bf16x8 qf[4], gf[4];
     frags_global(qf, Qb, ld, q0, T, lane);
     frags_global(gf, dOb, C, q0, T, lane);
-    const float L2 = (qi < T) ? p.lse_r[bh * T + qi] * LOG2E : 0.f;
+    const float L2 = p.lse_r[bh * T + (qi < T ? qi : T - 1)] * LOG2E;
     // delta_i = sum_d dO[i,d] O[i,d]: this lane holds half of row i of dO as MFMA fragments; dot it with the
     // matching half of O and add the other half-wave's part.  Written out for the dK/dV pass that follows.
     float dl = 0.f;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dQ[0][i] = 0.f; dQ[1][i] = 0.f; }
     const float sc = p.scale * LOG2E;
-    const uint32_t key = p.drop ? dg_site_key_dev(p.rng, p.site) : 0u;
+    const uint32_t key = DROP ? dg_site_key_dev(p.rng, p.site) : 0u;
     const uint32_t wbase = ((uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T) + 4u * hh) * DG_WEYL;
 
     u32x4 rk[4], rv[4];
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
             float pr = __builtin_amdgcn_exp2f(S[r] * sc - L2);
             if (kt == qb && kj > qi) pr = 0.f;
             float dp = dP[r];
-            if (p.drop) dp = dg_keep_w(key, wtile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DG_WEYL, p.thr) ? dp * p.inv_keep : 0.f;
+            if (DROP) dp = dg_keep_w(key, wtile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DG_WEYL, p.thr) ? dp * p.inv_keep : 0.f;
             S[r] = pr * (dp - dl);
         }
 #pragma unroll
@@ -335,6 +339,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
 // =============================================================================================
 // dK/dV: wave = 32 keys; per query tile: S = Q K^T, dP = dO V^T, dV += Pd^T dO, dK += dS^T Q
 #define WAVE_LDS_DKV 16384
+template <bool DROP>      // dropout on the probabilities (compile-time: no per-element uniform branch)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dK[0][i] = 0.f; dK[1][i] = 0.f; dV[0][i] = 0.f; dV[1][i] = 0.f; }
     const float sc = p.scale * LOG2E;
-    const uint32_t key = p.drop ? dg_site_key_dev(p.rng, p.site) : 0u;
+    const uint32_t key = DROP ? dg_site_key_dev(p.rng, p.site) : 0u;
     const float* lse = p.lse_r + bh * T;
     const float* dlt = p.delta_r + bh * T;
     const bool vec4 = (T % 4 == 0) && ((((uintptr_t)p.lse_r) & 15) == 0) && ((((uintptr_t)p.delta_r) & 15) == 0);
@@ -398,12 +403,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
             // rows q0 + 8g + 4hh + 0..3
             const int qr = q0 + 8 * g + 4 * hh;
             // row constants of 4 consecutive queries: one 16-byte load each instead of 8 scalar loads
-            f32x4 L4 = {0.f, 0.f, 0.f, 0.f}, D4 = {0.f, 0.f, 0.f, 0.f};
-            if (vec4 && qr + 3 < T) { L4 = *(const f32x4*)(lse + qr); D4 = *(const f32x4*)(dlt + qr); }
-            else {
+            f32x4 L4, D4;
+            if (vec4) {                                            // uniform; T % 4 == 0: clamp whole quads
+                const int qc = qr + 3 < T ? qr : T - 4;
+                L4 = *(const f32x4*)(lse + qc); D4 = *(const f32x4*)(dlt + qc);
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (qr + j < T) { L4[j] = lse[qr + j]; D4[j] = dlt[qr + j]; }
+                for (int j = 0; j < 4; ++j) {
+                    const int qc = qr + j < T ? qr + j : T - 1;
+                    L4[j] = lse[qc]; D4[j] = dlt[qc];
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
                 float pr = __builtin_amdgcn_exp2f(S[r] * sc - L2);
                 if ((qt == kb && kj > qi) || !ok) pr = 0.f;
                 float keepf = 1.f;
-                if (p.drop) keepf = dg_keep_w(key, wq + (uint32_t)(8 * g + j) * wrow, p.thr) ? p.inv_keep : 0.f;
+                if (DROP) keepf = dg_keep_w(key, wq + (uint32_t)(8 * g + j) * wrow, p.thr) ? p.inv_keep : 0.f;
                 Pd[r] = pr * keepf;
                 S[r] = pr * (dP[r] * keepf - dl);
             }
@@ -480,9 +489,11 @@ int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const f
     p.qkv = (const bf16_t*)qkv; p.out = (const bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv;
     p.lse_r = lse; p.delta = delta; p.delta_r = delta;
     dim3 grid((unsigned)((p.n_items + 3) / 4)), block(256);
-    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, block, 4 * WAVE_LDS_DQ, s, p);
+    if (p.drop) hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_DQ, s, p);
+    else hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, grid, block, 4 * WAVE_LDS_DQ, s, p);
     DG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, block, 4 * WAVE_LDS_DKV, s, p);
+    if (p.drop) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_DKV, s, p);
+    else hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<false>, grid, block, 4 * WAVE_LDS_DKV, s, p);
     DG_LAUNCH_CHECK();
     return DG_OK;
 }
