@@ -192,7 +192,15 @@ def kernel_roofline(eng, offsets, peak_tflops):
         if A.dtype == torch.bfloat16 and K % 64 == 0 and K >= 128:        # dispatch rule of dg_gemm_nt
             pf = kw.get("sign_bits") is not None                           # mask-bit prefetch variant
             nj = 6 if N % 192 == 0 else 4                                  # 128 x 192 tiles when they divide N
-            sym = f"gemm_nt_ws_kernel<{to},{'true' if pf else 'false'},{nj}>"
+            has = lambda k: kw.get(k) is not None and kw.get(k) is not False
+            drop = kw.get("dropout_p", 0.0) > 0.0 and kw.get("rng_state") is not None
+            opts = [has("bias"), has("relu"), has("relu_mask"), drop, has("residual"), has("sign_bits"), has("sign_bits_out")]
+            if not any(opts): epi = 1
+            elif to == "bf16" and opts == [True, True, False, False, False, False, True]: epi = 2
+            elif to == "float" and opts == [True, False, False, True, True, False, False]: epi = 3
+            elif to == "bf16" and opts == [False, False, False, False, False, True, False]: epi = 4
+            else: epi = 0
+            sym = f"gemm_nt_ws_kernel<{to},{'true' if pf else 'false'},{nj},{epi}>"      # dispatch rule of dg_gemm_nt
         else:
             sym = f"gemm_nt_kernel<{'bf16' if A.dtype == torch.bfloat16 else 'float'},{to}>"
         kw2 = dict(kw)

@@ -339,8 +339,23 @@ __global__ __launch_bounds__(512) void gemm_nt_glds_kernel(NtParams p) {
 // NJ = 16-column MFMA blocks per wave: 4 -> 128 x 128 tiles (wave tile 32 x 64), 6 -> 128 x 192 tiles (32 x 96).  The wide tile
 // makes N = 384 / 1152 / 1536 an exact number of rounds on 256 CUs at M = 16384 (256 / 768 / 1024 tiles; the square tile needs
 // 384 = 1.5 rounds for N = 384) and amortises the per-tile epilogue and barrier costs over 1.5x the MFMA work.
-template <typename TO, bool PF, int NJ>
+// EPI: which epilogue options exist at compile time.  0 = all of them behind run-time flags (any combination, plus the
+// DG_GEMM_DBG ablations and s_memtime stamps); 1 = plain store; 2 = bias + ReLU + sign-bit emission (Linear+ReLU of
+// FeedForward); 3 = bias + dropout + residual (proj / second FFN Linear); 4 = sign-bit mask (dX of the second FFN Linear).
+// The specialised forms are straight-line code: no uniform branch per option and per K step, so the scheduler can overlap
+// the epilogue's loads, lane exchanges and stores.
+template <typename TO, bool PF, int NJ, int EPI>
 __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
+    constexpr bool GEN = EPI == 0;
+    const float* const e_bias = (GEN || EPI == 2 || EPI == 3) ? p.bias : nullptr;
+    const int e_relu = GEN ? p.relu : (EPI == 2 ? 1 : 0);
+    const void* const e_mask = GEN ? p.relu_mask : nullptr;
+    const int e_drop = (GEN || EPI == 3) ? p.drop : 0;
+    const float* const e_res = (GEN || EPI == 3) ? p.residual : nullptr;
+    const unsigned char* const e_bin = (GEN || EPI == 4) ? p.bits_in : nullptr;
+    unsigned char* const e_bout = (GEN || EPI == 2) ? p.bits_out : nullptr;
+    const int e_dbg = GEN ? p.dbg : 0;
+    unsigned long long* const e_stamps = GEN ? p.stamps : nullptr;
     constexpr int BNW = NJ * 32;                               // tile width
     constexpr int STAGE = 16384 + BNW * 128;                   // A [128][128 B] + B [BNW][128 B]
     constexpr int PPA = WS_PPL, PPB = BNW / 8 / WS_NLOAD;      // 1 KB pieces per loader wave per stage
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     auto issue = [&](int g) {
         char* base = lds + (g & (GL_NST - 1)) * STAGE;
         const int64_t koff = (int64_t)iss_kt * 128;
-        if (!((p.dbg == 1 || p.dbg == 4) && g > 0)) {           // ablation: no operand traffic after the first stage
+        if (!((e_dbg == 1 || e_dbg == 4) && g > 0)) {           // ablation: no operand traffic after the first stage
 #pragma unroll
             for (int i = 0; i < PPA; ++i)
                 __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + (PPA * lw + i) * 1024), 16, 0, 0);
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
             for (int j = 0; j < NJ; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
     };
     uint32_t key = 0;
-    if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
+    if (e_drop) key = dg_site_key_dev(p.rng_state, p.site);
     TO* Cp = (TO*)p.C;
     const bool vok = p.vec_ok && (((p.ldc * sizeof(TO)) & 15) == 0) && (((uintptr_t)Cp & 15) == 0);
     // PF variant (sign_bits input: dX of FFN2): the mask bytes of an interior tile are fetched into registers
@@ -446,7 +461,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                 const int col = n0 + wn * (NJ * 16) + (2 * q + (fg & 1)) * 16 + (fg >> 1) * 8;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    pf_bits[q][i] = p.bits_in[((((int64_t)tile * 8 + wave) * (NJ / 2) + q) * 2 + i) * 64 + lane];
+                    pf_bits[q][i] = e_bin[((((int64_t)tile * 8 + wave) * (NJ / 2) + q) * 2 + i) * 64 + lane];
                 }
             }
         }
@@ -464,14 +479,14 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
             float bv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-            if (p.bias && col < p.N) {
+            if (e_bias && col < p.N) {
                 if (full) {
-                    const f32x4 b0 = *(const f32x4*)(p.bias + col), b1 = *(const f32x4*)(p.bias + col + 4);
+                    const f32x4 b0 = *(const f32x4*)(e_bias + col), b1 = *(const f32x4*)(e_bias + col + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
+                    for (int e = 0; e < 8; ++e) bv[e] = (col + e < p.N) ? e_bias[col + e] : 0.f;
                 }
             }
 #pragma unroll
@@ -489,22 +504,22 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                 acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (row >= p.M || col >= p.N) continue;
-                if (p.dbg >= 3 && v[0] != 12345.678f) continue;      // ablation: no stores
+                if (e_dbg >= 3 && v[0] != 12345.678f) continue;      // ablation: no stores
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += bv[e];
-                if (p.relu) {
+                if (e_relu) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                if (p.bits_in) {
+                if (e_bin) {
                     unsigned bm;
                     if (PF && pf_ok) bm = pf_bits[q][i];
-                    else bm = p.bits_in[((((int64_t)tile * 8 + wave) * (NJ / 2) + q) * 2 + i) * 64 + lane];
+                    else bm = e_bin[((((int64_t)tile * 8 + wave) * (NJ / 2) + q) * 2 + i) * 64 + lane];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = ((bm >> e) & 1u) ? v[e] : 0.f;
                 }
-                if (p.relu_mask) {
-                    const bf16_t* mp = (const bf16_t*)p.relu_mask + (int64_t)row * p.ldmask + col;
+                if (e_mask) {
+                    const bf16_t* mp = (const bf16_t*)e_mask + (int64_t)row * p.ldmask + col;
                     if (full && p.mask_vec_ok) {
                         const bf16x4 m0v = *(const bf16x4*)mp, m1v = *(const bf16x4*)(mp + 4);
 #pragma unroll
@@ -518,13 +533,13 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                             if (col + e < p.N) v[e] = (float)mp[e] > 0.f ? v[e] : 0.f;
                     }
                 }
-                if (p.drop) {
+                if (e_drop) {
                     const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
                 }
-                if (p.residual) {
-                    const float* rp = p.residual + (int64_t)row * p.ldr + col;
+                if (e_res) {
+                    const float* rp = e_res + (int64_t)row * p.ldr + col;
                     if (full) {
                         const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
 #pragma unroll
@@ -535,11 +550,11 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                             if (col + e < p.N) v[e] += rp[e];
                     }
                 }
-                if (p.bits_out) {                              // N % 8 == 0: the lane's 8 columns are all inside
+                if (e_bout) {                              // N % 8 == 0: the lane's 8 columns are all inside
                     unsigned bm = 0;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bm |= (v[e] > 0.f ? 1u : 0u) << e;
-                    p.bits_out[((((int64_t)tile * 8 + wave) * (NJ / 2) + q) * 2 + i) * 64 + lane] = (unsigned char)bm;   // 64 contiguous bytes per wave
+                    e_bout[((((int64_t)tile * 8 + wave) * (NJ / 2) + q) * 2 + i) * 64 + lane] = (unsigned char)bm;   // 64 contiguous bytes per wave
                 }
                 TO* cp = Cp + (int64_t)row * p.ldc + col;
                 if (full) {
@@ -564,7 +579,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
 
     int nstamp = 0;
     auto stamp = [&]() {
-        if (p.stamps && tid == 0 && nstamp < 64) p.stamps[(size_t)blockIdx.x * 64 + nstamp] = __builtin_amdgcn_s_memtime();
+        if (e_stamps && tid == 0 && nstamp < 64) e_stamps[(size_t)blockIdx.x * 64 + nstamp] = __builtin_amdgcn_s_memtime();
         ++nstamp;
     };
     stamp();
@@ -578,12 +593,12 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     for (int g = 0; g < total; ++g) {
         const char* buf = lds + (g & (GL_NST - 1)) * STAGE;
         if (PF && kt == pf_at) prefetch_operands(tile_i);
-        if (p.dbg != 2) { read_frags(fa1, fb1, buf, 1); mma_all(fa0, fb0); }
+        if (e_dbg != 2) { read_frags(fa1, fb1, buf, 1); mma_all(fa0, fb0); }
         if (g + 1 < total) {
             __builtin_amdgcn_s_barrier();                          // stage g+1 is visible; nothing to wait for here
-            if (p.dbg != 2) read_frags(fa0, fb0, lds + ((g + 1) & (GL_NST - 1)) * STAGE, 0);
+            if (e_dbg != 2) read_frags(fa0, fb0, lds + ((g + 1) & (GL_NST - 1)) * STAGE, 0);
         }
-        if (p.dbg != 2) mma_all(fa1, fb1);
+        if (e_dbg != 2) mma_all(fa1, fb1);
         stamp();
         if (++kt == nk) { epilogue(tile_i); kt = 0; ++tile_i; stamp(); }
     }
@@ -1319,11 +1334,27 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
             pgrid = dim3(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
         }
         const dim3 wsb(512 + 64 * WS_NLOAD);
+        // epilogue specialisation (see the kernel's EPI parameter); anything else, and every debug run, takes the generic form
+        int epi = 0;
+        {
+            const bool plain = !a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits && !a->sign_bits_out;
+            if (p.dbg == 0 && !p.stamps) {
+                if (plain) epi = 1;
+                else if (a->out_dtype == DG_BF16 && a->bias && a->relu && a->sign_bits_out && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits) epi = 2;
+                else if (a->out_dtype == DG_F32 && a->bias && p.drop && a->residual && !a->relu && !a->relu_mask && !a->sign_bits && !a->sign_bits_out) epi = 3;
+                else if (a->out_dtype == DG_BF16 && pf && !a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits_out) epi = 4;
+            }
+        }
 #define DG_WS_LAUNCH(NJ_) do { \
-            if (pf && a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true, NJ_>), pgrid, wsb, 0, s, p); \
-            else if (pf) hipLaunchKernelGGL((gemm_nt_ws_kernel<float, true, NJ_>), pgrid, wsb, 0, s, p); \
-            else if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, NJ_>), pgrid, wsb, 0, s, p); \
-            else hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, NJ_>), pgrid, wsb, 0, s, p); } while (0)
+            if (epi == 1 && a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, NJ_, 1>), pgrid, wsb, 0, s, p); \
+            else if (epi == 1) hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, NJ_, 1>), pgrid, wsb, 0, s, p); \
+            else if (epi == 2) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, NJ_, 2>), pgrid, wsb, 0, s, p); \
+            else if (epi == 3) hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, NJ_, 3>), pgrid, wsb, 0, s, p); \
+            else if (epi == 4) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true, NJ_, 4>), pgrid, wsb, 0, s, p); \
+            else if (pf && a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true, NJ_, 0>), pgrid, wsb, 0, s, p); \
+            else if (pf) hipLaunchKernelGGL((gemm_nt_ws_kernel<float, true, NJ_, 0>), pgrid, wsb, 0, s, p); \
+            else if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, NJ_, 0>), pgrid, wsb, 0, s, p); \
+            else hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, NJ_, 0>), pgrid, wsb, 0, s, p); } while (0)
         if (wide) DG_WS_LAUNCH(6); else DG_WS_LAUNCH(4);
 #undef DG_WS_LAUNCH
     } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 2) {
