@@ -577,6 +577,94 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
         return vok && (m0 + BM <= p.M) && (n0 + BNW <= p.N);
     };
 
+    // Interior tiles of the specialised forms: no per-lane bounds checks (the compiler turned those into ~10 exec-mask
+    // branches per 16-row block, with the residual loads issued right in front of their use = one HBM round trip per block),
+    // and the bias / residual operands of block q+1 are requested before block q is computed and stored.
+    auto epilogue_fast = [&](int tile, int m0, int n0) {
+        const int col0 = n0 + wn * (NJ * 16) + (fg & 1) * 16 + (fg >> 1) * 8;       // + 32 q
+        const int row0 = m0 + wm * 32 + fr;                                        // + 16 i
+        f32x4 bq[2][2];                // [q & 1][half]
+        f32x4 rq[2][2][2];             // [q & 1][i][half]
+        auto request = [&](int q) {
+            const int col = col0 + 32 * q;
+            if (e_bias) { bq[q & 1][0] = *(const f32x4*)(e_bias + col); bq[q & 1][1] = *(const f32x4*)(e_bias + col + 4); }
+            if (e_res) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float* rp = e_res + (int64_t)(row0 + 16 * i) * p.ldr + col;
+                    rq[q & 1][i][0] = *(const f32x4*)rp; rq[q & 1][i][1] = *(const f32x4*)(rp + 4);
+                }
+            }
+        };
+        request(0);
+#pragma unroll
+        for (int q = 0; q < NJ / 2; ++q) {
+            if (q + 1 < NJ / 2) request(q + 1);
+            const int col = col0 + 32 * q;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = row0 + 16 * i;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][2 * q][e], y = acc[i][2 * q + 1][e];
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+                    v[e] = x;
+                    v[4 + e] = y;
+                }
+                acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (e_bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += bq[q & 1][0][e]; v[4 + e] += bq[q & 1][1][e]; }
+                }
+                if (e_relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (e_bin) {
+                    const unsigned bm = PF ? (unsigned)pf_bits[q][i] : (unsigned)e_bin[((((int64_t)tile * 8 + wave) * (NJ / 2) + q) * 2 + i) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ((bm >> e) & 1u) ? v[e] : 0.f;
+                }
+                if (e_drop) {
+                    const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
+                }
+                if (e_res) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += rq[q & 1][i][0][e]; v[4 + e] += rq[q & 1][i][1][e]; }
+                }
+                if (e_bout) {
+                    unsigned bm = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bm |= (v[e] > 0.f ? 1u : 0u) << e;
+                    e_bout[((((int64_t)tile * 8 + wave) * (NJ / 2) + q) * 2 + i) * 64 + lane] = (unsigned char)bm;
+                }
+                TO* cp = Cp + (int64_t)row * p.ldc + col;
+                if constexpr (sizeof(TO) == 4) {
+                    *(f32x4*)cp = (f32x4){v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                    *(bf16x8*)cp = o;
+                }
+            }
+        }
+    };
+    auto finish_tile = [&](int ti) {
+        if constexpr (EPI != 0) {
+            const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
+            const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BNW;
+            // (PF: pf_ok was computed for this very tile two K steps ago and means "interior")
+            if (vok && (m0 + BM <= p.M) && (n0 + BNW <= p.N) && (!PF || pf_ok)) { epilogue_fast(tile, m0, n0); return; }
+        }
+        epilogue(ti);
+    };
+
     int nstamp = 0;
     auto stamp = [&]() {
         if (e_stamps && tid == 0 && nstamp < 64) e_stamps[(size_t)blockIdx.x * 64 + nstamp] = __builtin_amdgcn_s_memtime();
@@ -600,7 +688,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
         }
         if (e_dbg != 2) mma_all(fa1, fb1);
         stamp();
-        if (++kt == nk) { epilogue(tile_i); kt = 0; ++tile_i; stamp(); }
+        if (++kt == nk) { finish_tile(tile_i); kt = 0; ++tile_i; stamp(); }
     }
 }
 
