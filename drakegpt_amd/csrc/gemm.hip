@@ -2087,33 +2087,50 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
         if (gp.splits == 2) {
             float* part = (float*)(gp.ws + ((size_t)cx.tile * 8 + wave) * 16384);
             unsigned* flag = (unsigned*)(gp.ws + (size_t)gp.total_tiles * 8 * 16384) + cx.tile * 8 + wave;
+            // The 16 KB of a wave move as 16 x (64 lanes x 16 B) with the sc0 sc1 cache bits: system-scope write-through
+            // stores and L2-bypassing loads, i.e. coherent between XCDs without any cache-wide maintenance.  (One relaxed
+            // agent-scope atomic per float -- the portable spelling -- cost ~30 us per hand-over.)
+            char* pw = (char*)part + lane * 16;
             if (cx.half == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            __hip_atomic_store(part + ((i * 4 + j) * 4 + e) * 64 + lane, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(pw + (i * 4 + j) * 1024), "v"(acc[i][j]) : "memory");
                     }
-                // The partial sums and the flag are agent-scope atomic accesses (performed at the level all XCDs share), so
-                // ordering them needs only "my stores have been acknowledged": a workgroup-scope fence.  An agent-scope
-                // release / acquire pair would write back and invalidate the whole L2 of the XCD on every hand-over, which
-                // made this kernel 2x slower than not splitting at all.
+                // the flag is an agent-scope atomic too, so ordering needs only "my stores have been acknowledged": a
+                // workgroup-scope fence.  An agent-scope release / acquire pair would write back and invalidate the whole L2
+                // of the XCD on every hand-over, which made this kernel 2x slower than not splitting at all.
+                // The accumulators pass through the wait: that keeps their registers allocated and untouched until every
+                // store has read its data (the hazard logic that protects a store's data registers does not see through
+                // inline asm -- without this the compiler recycled them for the next store's address).
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]), "+v"(acc[1][1]),
+                               "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]),
+                               "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3])
+                             :: "memory");
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 return;
             }
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            f32x4 t[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(t[k]) : "v"(pw + k * 1024) : "memory");
+            // one wait for all sixteen; the values pass through it so that nothing reads them earlier
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
+                           "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15])
+                         :: "memory");
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc[i][j][e] += __hip_atomic_load(part + ((i * 4 + j) * 4 + e) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int j = 0; j < 4; ++j) acc[i][j] += t[i * 4 + j];
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
