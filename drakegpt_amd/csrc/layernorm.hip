@@ -150,8 +150,16 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
             typedef TD TD4 __attribute__((ext_vector_type(4)));
             const TD4* dyr = (const TD4*)(dy + (int64_t)row * C);
             const f32x4* xr = (const f32x4*)(x + (int64_t)row * C);
-            f32x4 gv[LN_MAXV], xh[LN_MAXV];
+            f32x4 gv[LN_MAXV], xh[LN_MAXV], drv[LN_MAXV];
             float s1 = 0.f, s2 = 0.f;
+            // the residual-branch gradient is requested together with dy and x, not after the two reductions (that cost a
+            // second HBM round trip per row)
+            const f32x4* drr = dresid ? (const f32x4*)(dresid + (int64_t)row * C) : nullptr;
+#pragma unroll
+            for (int k = 0; k < LN_MAXV; ++k) {
+                const int i = lane + k * 64;
+                drv[k] = (drr && i < nv) ? drr[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int k = 0; k < LN_MAXV; ++k) {
                 int i = lane + k * 64;
@@ -171,7 +179,6 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
             }
             const float c1 = wave_sum(s1) * invC, c2 = wave_sum(s2) * invC;
             f32x4* dxr = (f32x4*)(dx + (int64_t)row * C);
-            const f32x4* drr = dresid ? (const f32x4*)(dresid + (int64_t)row * C) : nullptr;
 #pragma unroll
             for (int k = 0; k < LN_MAXV; ++k) {
                 int i = lane + k * 64;
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
                     f32x4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = rs * (gv[k][j] - c1 - xh[k][j] * c2);
-                    if (drr) o += drr[i];
+                    o += drv[k];
                     dxr[i] = o;
                     if (FUSE_G) {
                         f32x4 gq = o;
