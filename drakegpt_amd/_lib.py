@@ -75,7 +75,8 @@ SIGNATURES = {
     "dg_transpose_cast": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp],
     "dg_transpose_cast_batched": [_vp, _i, _i, _i, _vp],
     "dg_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
-    "dg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
+    "dg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
+    "dg_attn_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
     "dg_attn_decode": [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dg_cross_entropy": [_vp, _i64, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _i, _vp],
     "dg_reduce_sum": [_vp, _i64, _f, _vp, _vp],
@@ -99,6 +100,7 @@ def _load() -> C.CDLL:
         fn.restype = C.c_int
     lib.dg_gemm_nt_sign_bits_bytes.restype = C.c_int64
     lib.dg_gemm_tn_grouped_workspace_bytes.restype = C.c_int64
+    lib.dg_attn_bwd_workspace_bytes.restype = C.c_int64
     lib.dg_error_string.argtypes = [C.c_int]
     lib.dg_error_string.restype = C.c_char_p
     v = lib.dg_version()

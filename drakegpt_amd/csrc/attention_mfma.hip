@@ -35,7 +35,11 @@ struct AttnP {
     float scale;
     int drop; float inv_keep; uint32_t thr; const uint32_t* rng; uint32_t site;
     int balance, rot_div;      // balance: 0 plain, 1 = cost-balanced item order (nblk % 4 == 0); rot_div = #CUs
+    char* tiles;               // optional: [B*NH][nblk(nblk+1)/2] tiles of 4 KB, see attn_bwd_dq_mfma_kernel
 };
+__device__ __forceinline__ int64_t attn_tile_index(const AttnP& p, int64_t bh, int qb, int kb) {
+    return (bh * (p.nblk * (p.nblk + 1) / 2) + qb * (qb + 1) / 2 + kb) * 4096;
+}
 
 // Which 32-row block does this wave work on?  A causal block b costs b+1 tile iterations (nblk-b for the dK/dV
 // kernel), so "4 consecutive blocks per workgroup" gave workgroups of cost 26 and 10 at T = 256, and since a CU
@@ -315,14 +319,45 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
         }
         const int k0 = kt * TILE;
         const uint32_t wtile = wbase + (uint32_t)k0 * DG_WEYL;
+        // With p.tiles the (dropped-out) probabilities and dS of this 32 x 32 tile are also written out, side by side as a
+        // [32 queries][P: 32 keys | dS: 32 keys] bf16 image, for attn_bwd_dkv_tiles_kernel: the dK/dV pass then needs no
+        // score recomputation at all.  Staged through the V image (its MFMAs are done) so that the store is four full
+        // 1 KB rows per instruction.
+        const bool emit = p.tiles != nullptr;
+        const bool rows_ok = q0 + TILE <= T;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kj = k0 + krow(r, hh);
-            float pr = __builtin_amdgcn_exp2f(S[r] * sc - L2);
-            if (kt == qb && kj > qi) pr = 0.f;
-            float dp = dP[r];
-            if (DROP) dp = dg_keep_w(key, wtile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DG_WEYL, p.thr) ? dp * p.inv_keep : 0.f;
-            S[r] = pr * (dp - dl);
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 pv, dv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g + j;
+                const int kj = k0 + krow(r, hh);
+                float pr = __builtin_amdgcn_exp2f(S[r] * sc - L2);
+                if (kt == qb && kj > qi) pr = 0.f;
+                float kf = 1.f;
+                if (DROP) kf = dg_keep_w(key, wtile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DG_WEYL, p.thr) ? p.inv_keep : 0.f;
+                const float ds = pr * (dP[r] * kf - dl);
+                S[r] = ds;
+                pv[j] = (bf16_t)(pr * kf);
+                dv[j] = (bf16_t)ds;
+            }
+            if (emit) {
+                if (!rows_ok && qi >= T) {                         // query rows past the sequence end (last, ragged block only)
+                    pv = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                    dv = pv;
+                }
+                *(bf16x4*)(imgV + c * 128 + (8 * g + 4 * hh) * 2) = pv;
+                *(bf16x4*)(imgV + c * 128 + 64 + (8 * g + 4 * hh) * 2) = dv;
+            }
+        }
+        if (emit) {
+            __builtin_amdgcn_wave_barrier();
+            char* tb = p.tiles + attn_tile_index(p, bh, qb, kt);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cc = lane + 64 * i;
+                *(u32x4*)(tb + cc * 16) = *(const u32x4*)(imgV + cc * 16);
+            }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -451,6 +486,67 @@ bool dg_attn_mfma_supported(int B, int T, int NH, int H) {
     return H == HD && B > 0 && T > 0 && NH > 0 && (int64_t)B * NH * T * T < ((int64_t)1 << 32);
 }
 
+
+// =============================================================================================
+// dK/dV from the tiles the dQ pass wrote: wave = 32 keys; per query tile: dV += Pd^T dO, dK += dS^T Q.  No scores, no exp,
+// no dropout hash, no K / V operands: 8 MFMAs per tile, three 4 KB tiles staged per iteration (P|dS, Q, dO), all read
+// with transposed LDS reads.  ~140 VGPRs, 12 KB of LDS per wave: three workgroups per CU, every wave resident at once.
+#define WAVE_LDS_DKVT 12288
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_tiles_kernel(AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t bh; int blk; bool valid;
+    attn_item(p, wave, bh, blk, valid);
+    if (!valid) return;
+    char* imgP = smem + wave * WAVE_LDS_DKVT;     // [32 q][P 32 | dS 32]
+    char* imgQt = imgP + 4096;
+    char* imgGt = imgP + 8192;
+    const int kb = p.balance ? p.nblk - 1 - blk : blk;       // low key blocks see the most queries: heavy first
+    const int h = (int)(bh % p.NH), b = (int)(bh / p.NH);
+    const int T = p.T, C = p.NH * HD;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16_t* Qb = p.qkv + (int64_t)b * T * ld + h * HD;
+    const bf16_t* dOb = p.dout + (int64_t)b * T * C + h * HD;
+    const int k0 = kb * TILE;
+    f32x16 dK[2], dV[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dK[0][i] = 0.f; dK[1][i] = 0.f; dV[0][i] = 0.f; dV[1][i] = 0.f; }
+    auto load_pt = [&](u32x4 (&r)[4], int qt) {
+        const char* tb = p.tiles + attn_tile_index(p, bh, qt, kb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *(const u32x4*)(tb + (lane + 64 * i) * 16);
+    };
+    u32x4 rp[4], rq[4], rg[4];
+    load_pt(rp, kb);
+    tile_load(rq, Qb, ld, k0, T, lane);
+    tile_load(rg, dOb, C, k0, T, lane);
+    for (int qt = kb; qt < p.nblk; ++qt) {
+        tile_store<true>(imgP, rp, lane);
+        tile_store<true>(imgQt, rq, lane);
+        tile_store<true>(imgGt, rg, lane);
+        if (qt + 1 < p.nblk) {
+            load_pt(rp, qt + 1);
+            tile_load(rq, Qb, ld, (qt + 1) * TILE, T, lane);
+            tile_load(rg, dOb, C, (qt + 1) * TILE, T, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 pf = frag_tr(imgP, 0, s, lane), df = frag_tr(imgP, 1, s, lane);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag_tr(imgGt, dt, s, lane), dV[dt], 0, 0, 0);
+                dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, frag_tr(imgQt, dt, s, lane), dK[dt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    bf16_t* dKb = p.dqkv + (int64_t)b * T * ld + C + h * HD;
+    store_N_acc(imgP, dK, p.scale, dKb, ld, k0, T, lane);
+    __builtin_amdgcn_wave_barrier();
+    store_N_acc(imgP, dV, 1.f, dKb + C, ld, k0, T, lane);
+}
+
 static void fill(AttnP& p, int B, int T, int NH, float scale, float dp, const uint32_t* rng, uint32_t site) {
     p.B = B; p.T = T; p.NH = NH; p.nblk = (T + TILE - 1) / TILE;
     p.n_items = (int64_t)B * NH * p.nblk;
@@ -481,18 +577,28 @@ int dg_attn_fwd_mfma(const void* qkv, void* out, float* lse, int B, int T, int N
     return DG_OK;
 }
 
-int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
+// bytes of the optional P|dS tile scratch behind the [B,NH,T] delta floats (0 = shape not covered)
+int64_t dg_attn_bwd_mfma_tile_bytes(int B, int T, int NH) {
+    const int64_t nblk = (T + TILE - 1) / TILE;
+    return (int64_t)B * NH * (nblk * (nblk + 1) / 2) * 4096;
+}
+
+int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, void* tiles,
                      int B, int T, int NH, int H, float scale, float dp, const uint32_t* rng, uint32_t site, hipStream_t s) {
     if (dp < 0.f || dp >= 1.f || !dg_aligned16(qkv) || !dg_aligned16(out) || !dg_aligned16(dout) || !dg_aligned16(dqkv)) return DG_ERR_ARG;
+    if (tiles && !dg_aligned16(tiles)) return DG_ERR_ALIGN;
     AttnP p = {};
     fill(p, B, T, NH, scale, dp, rng, site);
     p.qkv = (const bf16_t*)qkv; p.out = (const bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv;
     p.lse_r = lse; p.delta = delta; p.delta_r = delta;
+    static const int tile_mode = [] { const char* e = getenv("DG_ATTN_TILES"); return e ? atoi(e) : 1; }();   // 0 = recompute in the dK/dV pass (A/B runs)
+    p.tiles = tile_mode ? (char*)tiles : nullptr;
     dim3 grid((unsigned)((p.n_items + 3) / 4)), block(256);
     if (p.drop) hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_DQ, s, p);
     else hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, grid, block, 4 * WAVE_LDS_DQ, s, p);
     DG_LAUNCH_CHECK();
-    if (p.drop) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_DKV, s, p);
+    if (p.tiles) hipLaunchKernelGGL(attn_bwd_dkv_tiles_kernel, grid, block, 4 * WAVE_LDS_DKVT, s, p);
+    else if (p.drop) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_DKV, s, p);
     else hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<false>, grid, block, 4 * WAVE_LDS_DKV, s, p);
     DG_LAUNCH_CHECK();
     return DG_OK;

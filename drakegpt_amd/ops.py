@@ -340,8 +340,8 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, T: int
     _chk(dout, "dout", qkv.dtype)
     _chk(lse, "lse", torch.float32)
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty((B, NH, T), dtype=torch.float32, device=qkv.device)
-    check(lib.dg_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(delta), B, T, NH, H, float(scale), float(p),
+    ws = torch.empty(int(lib.dg_attn_bwd_workspace_bytes(B, T, NH, H, dt_code(qkv.dtype))), dtype=torch.uint8, device=qkv.device)
+    check(lib.dg_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(ws), ws.numel(), B, T, NH, H, float(scale), float(p),
                           _p(rng_state) if p > 0.0 else None, site, dt_code(qkv.dtype), _stream()), "dg_attn_bwd")
     return dqkv
 

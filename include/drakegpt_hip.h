@@ -201,9 +201,13 @@ int dg_transpose_cast_batched(const int64_t* desc, int n_desc, int total_tiles, 
 int dg_attn_fwd(const void* qkv, void* out, float* lse, int B, int T, int NH, int H,
                 float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
                 int dtype, void* stream);
-/* dqkv [B*T, 3*NH*H] from dout; delta_ws: workspace [B,NH,T] floats. */
+/* dqkv [B*T, 3*NH*H] from dout.  workspace: at least B*NH*T floats (delta = rowsum(dO * O)); with
+ * dg_attn_bwd_workspace_bytes(...) bytes the dQ pass also leaves the dropped-out probabilities and dS of every
+ * unmasked 32 x 32 tile behind it and the dK/dV pass consumes them instead of recomputing scores, exp and the
+ * dropout hash (bf16, head size 64; 55 MB at the scaled config). */
+int64_t dg_attn_bwd_workspace_bytes(int B, int T, int NH, int H, int dtype);
 int dg_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
-                void* dqkv, float* delta_ws, int B, int T, int NH, int H,
+                void* dqkv, void* workspace, int64_t workspace_bytes, int B, int T, int NH, int H,
                 float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
                 int dtype, void* stream);
 
