@@ -44,6 +44,8 @@ def short(name):
         return f"{m.group(1)}<{','.join(out)}>"
     name = re.sub(r"\(.*", "", name)
     name = name.replace("void ", "").replace(", ", ",")
+    # rocprofv3's demangler garbles __bf16 / true template arguments: "<bool _Accum,bool,E,6,4>" is <bf16,true,6,4>
+    name = name.replace("bool _Accum", "bf16").replace(",bool,E", ",true")
     return name.strip()
 
 
