@@ -4,16 +4,21 @@
 //                the 16x16 MFMA A/B fragment shape (8 bf16 / 4 f32 consecutive k per lane), so
 //                fragments are single 16-byte LDS reads.  Forward Linears use B = W [out,in];
 //                dX GEMMs use B = W^T (kept as a second shadow copy, refreshed by the optimizer).
-//   dg_gemm_tn : dW[P,Q] = sum_r A[r,P] B[r,Q]    -- contraction over the strided row index; bf16
-//                fragments come from ds_read_b64_tr_b16 (hardware transpose read), f32 fragments
-//                from plain 4-byte reads.  Split over r, fp32 partial slabs (no atomics).
+//   dg_gemm_tn(_grouped) : dW[P,Q] = sum_r A[r,P] B[r,Q]  -- contraction over the strided row index;
+//                bf16 fragments come from ds_read_b64_tr_b16 (hardware transpose read), f32 fragments
+//                from plain 4-byte reads.
 //
-// Structure (both): 128x128 output tile per 256-thread workgroup, 2x2 waves of 64x64 (4x4 MFMA
-// 16x16 tiles per wave, fp32 accumulators), K step = 128 bytes per row, global -> registers ->
-// LDS staging with the next tile's loads issued before the current tile's MFMAs (cdna guide T14),
-// double-buffered LDS (one barrier per K step), XOR-swizzled LDS rows (T2), XCD-aware tile order
-// (T1).  bf16: v_mfma_f32_16x16x32_bf16; f32 (parity mode): v_mfma_f32_16x16x4_f32, which is
-// bit-exact fp32 FMA accumulation (guide section 3, "FP32-input MFMA").
+// Kernels in this file:
+//   gemm_nt_ws_kernel          bf16, the default: persistent, 4 LDS-DMA loader waves + 8 MFMA waves per CU,
+//                              128x192 / 128x128 tiles, register-only epilogue with compile-time variants
+//   gemm_nt_kernel             fp32 parity mode (v_mfma_f32_16x16x4_f32 = exact fp32 FMA accumulation) and bf16
+//                              shapes the default does not cover: 128x128 tile / 256 threads, register-prefetched
+//                              global -> LDS staging, double-buffered XOR-swizzled LDS, LDS-staged epilogue
+//   gemm_tn_grouped256_kernel  all dW of a backward pass in one launch, 256x128 tiles, chained K halves
+//   gemm_tn_grouped_kernel     the same with 128x128 tiles (DG_TN_TILE=128)
+//   gemm_tn_ws_kernel, gemm_tn_bf16_kernel, gemm_tn_f32_kernel   one dW per launch, split-K fp32 slabs
+// Earlier variants that were measured slower (LDS-DMA without loader waves, one tile per workgroup, 256x128 NT
+// tiles, two co-resident workgroups per CU) are in the history of this file and listed in DESIGN.md section 4.
 #include "common.h"
 #include <stdlib.h>
 
@@ -222,106 +227,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
             for (int r = 0; r < 4; ++r) stage[(i * 16 + fg * 4 + r) * EPI_PITCH + j * 16 + fr] = acc[i][j][r];
     __builtin_amdgcn_wave_barrier();
     nt_epilogue<T, TO, 64>(stage, m0 + wm * 64, n0 + wn * 64, p, lane);
-}
-
-// ---------------------------------------------------------------------------------------------
-// bf16 NT GEMM with a 4-stage global_load_lds pipeline (K % 64 == 0).  The register-staged kernel
-// above keeps one K step of loads in flight, which leaves the K = 384..1536 shapes of the training
-// step latency-bound; here LDS-DMA writes the XOR-swizzled image directly (linear destination,
-// permuted per-lane SOURCE chunk -- guide rule 21), three stages stay in flight across the single
-// raw s_barrier of a K step, and waits are counted (never vmcnt(0) inside the loop).
-// 512 threads = 8 waves (4 x 2) of 32 x 64, two waves per SIMD; 128 KB LDS, one workgroup per CU.
-
-template <typename TO>
-__global__ __launch_bounds__(512) void gemm_nt_glds_kernel(NtParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tile = dg_xcd_remap(blockIdx.x, p.n_tiles);
-    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-    const int nk = p.K / 64;
-
-    // LDS-DMA pieces: one wave instruction = 1 KB = 8 rows x 128 B.  Lane (prow, slot) lands on
-    // row*128 + slot*16, so it must fetch chunk = slot ^ (row & 7) = slot ^ prow of its row.
-    const int prow = lane >> 3, slot = lane & 7;
-    const int chunk = slot ^ prow;
-    const char* srcA[2];
-    const char* srcB[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (2 * wave + i) * 8 + prow;
-        int gm = m0 + row; if (gm > p.M - 1) gm = p.M - 1;      // rows past the edge: any finite data,
-        int gn = n0 + row; if (gn > p.N - 1) gn = p.N - 1;      // they only feed outputs that are not stored
-        srcA[i] = p.A + (int64_t)gm * p.lda_b + chunk * 16;
-        srcB[i] = p.B + (int64_t)gn * p.ldb_b + chunk * 16;
-    }
-    auto issue = [&](int kt) {
-        char* base = lds + (kt & (GL_NST - 1)) * GL_STAGE + (2 * wave) * 1024;
-        const int64_t koff = (int64_t)kt * 128;
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[0] + koff), (lptr_t)(base), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[1] + koff), (lptr_t)(base + 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcB[0] + koff), (lptr_t)(base + 16384), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcB[1] + koff), (lptr_t)(base + 16384 + 1024), 16, 0, 0);
-    };
-
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int npre = nk < GL_NST - 1 ? nk : GL_NST - 1;
-    for (int s = 0; s < npre; ++s) issue(s);
-    const int fr = lane & 15, fg = lane >> 4;
-    const int offA0 = nt_lds_off(wm * 32 + fr, fg), offB0 = nt_lds_off(wn * 64 + fr, fg);   // ks = 0 chunk fg; ks = 1 is chunk 4+fg
-    auto read_frags = [&](u32x4 (&fa)[2], u32x4 (&fb)[4], const char* buf, int ks) {
-        // rows +16*i keep row&7, so the swizzled chunk offset is the same for every i / j
-        const int ka = nt_lds_off(wm * 32 + fr, ks * 4 + fg) , kb = nt_lds_off(wn * 64 + fr, ks * 4 + fg);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(buf + ka + i * 16 * 128);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(buf + 16384 + kb + j * 16 * 128);
-    };
-    auto mma_all = [&](const u32x4 (&fa)[2], const u32x4 (&fb)[4]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mma16<bf16_t>(fa[i], fb[j], acc[i][j]);
-    };
-    (void)offA0; (void)offB0;
-    // software pipeline: the fragments of the NEXT half K-step are always in flight under the
-    // MFMAs of the current one; the stage hand-over (counted wait + raw barrier + refill) sits in
-    // the middle of a K step, between the two MFMA batches.
-    u32x4 fa0[2], fb0[4], fa1[2], fb1[4];
-    if (npre >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (GL_NST - 2)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (npre == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    read_frags(fa0, fb0, lds, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* buf = lds + (kt & (GL_NST - 1)) * GL_STAGE;
-        read_frags(fa1, fb1, buf, 1);
-        mma_all(fa0, fb0);
-        if (kt + 1 < nk) {
-            int issued = kt + GL_NST - 1; if (issued > nk) issued = nk;
-            if (issued - (kt + 2) >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage kt+1 landed, kt+2 may fly
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                        // ... for every wave; stage kt-1 is fully consumed
-            if (kt + GL_NST - 1 < nk) issue(kt + GL_NST - 1);    // refills stage kt-1's buffer
-            read_frags(fa0, fb0, lds + ((kt + 1) & (GL_NST - 1)) * GL_STAGE, 0);
-        }
-        mma_all(fa1, fb1);
-    }
-    __syncthreads();                                         // every wave is done with the operand buffers
-    float* stage = (float*)lds + wave * (32 * EPI_PITCH);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) stage[(i * 16 + fg * 4 + r) * EPI_PITCH + j * 16 + fr] = acc[i][j][r];
-    __builtin_amdgcn_wave_barrier();
-    nt_epilogue<bf16_t, TO, 32>(stage, m0 + wm * 32, n0 + wn * 64, p, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -692,641 +597,11 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Paired-workgroup EXPERIMENT (DG_GEMM_NT=6; measured 20-35% SLOWER than gemm_nt_ws_kernel on every shape of the
-// step, so not the default -- kept for the register-only epilogue): TWO 384-thread workgroups share a CU (80 KB of LDS and 6 waves
-// each: 4 MFMA waves in 2x2 with 64x64 wave tiles + 2 loader waves), so while one workgroup sits in
-// its epilogue, its first-stage latency or a barrier, the other one keeps the MFMA pipes busy -- the
-// one-workgroup-per-CU kernels above spend ~45% of a K = 384 tile in the epilogue with the matrix
-// cores idle (measured: tools/gemm_stamps.py, DG_GEMM_DBG ablations).  Differences from gemm_nt_ws_kernel:
-//   * K step of 32 (stage = 2 x [128 rows][64 B] = 16 KB), five stages in a ring; a stage is issued
-//     three barriers before it is read;
-//   * 64x64 wave tiles: 8 fragment reads per 16 MFMAs (the 32x64 tiles needed 12);
-//   * no LDS staging in the epilogue: v_permlane16_swap exchanges accumulator quads between lane
-//     rows so that every lane owns 8 consecutive output columns and stores 16 B (bf16) / 2 x 16 B (fp32).
-#define PP_BK 32
-#define PP_NS 5
-#define PP_STAGE 16384
-// [128 rows][64 B] operand image: 16-byte slot XORed with (row>>2)&3 -- conflict-free for the
-// fragment reads (16 rows x one k-chunk per quarter wave) and realised on the LDS-DMA source side.
-__device__ __forceinline__ int pp_lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
-
-template <typename TO>
-__global__ __launch_bounds__(384, 2) void gemm_nt_pp_kernel(NtParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[PP_NS * PP_STAGE];      // 80 KB: two workgroups fill the CU's 160 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G = gridDim.x;
-    const int my_tiles = (p.n_tiles - (int)blockIdx.x + G - 1) / G;
-    const int nk = p.K / PP_BK;
-    const int total = my_tiles * nk;
-
-    if (wave >= 4) {
-        // ---- loader role: per stage 4 + 4 LDS-DMA pieces of 1 KB (16 rows x 64 B) per wave
-        const int lw = wave - 4;
-        const int prow = lane >> 2, slot = lane & 3;
-        const int chunk = slot ^ ((prow >> 2) & 3);
-        const char* srcA[4];
-        const char* srcB[4];
-        auto set_src = [&](int ti) {
-            const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
-            const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = (lw * 4 + i) * 16 + prow;
-                int gm = m0 + row; if (gm > p.M - 1) gm = p.M - 1;
-                int gn = n0 + row; if (gn > p.N - 1) gn = p.N - 1;
-                srcA[i] = p.A + (int64_t)gm * p.lda_b + chunk * 16;
-                srcB[i] = p.B + (int64_t)gn * p.ldb_b + chunk * 16;
-            }
-        };
-        int iss_tile = 0, iss_kt = 0, iss_buf = 0;
-        auto issue = [&]() {
-            char* base = lds + iss_buf * PP_STAGE + (lw * 4) * 1024;
-            const int64_t koff = (int64_t)iss_kt * (PP_BK * 2);
-            if (!((p.dbg == 1 || p.dbg == 4) && (iss_tile | iss_kt)))     // ablation: no operand traffic after the first stage
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + i * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + koff), (lptr_t)(base + 8192 + i * 1024), 16, 0, 0);
-            }
-            if (++iss_buf == PP_NS) iss_buf = 0;
-            if (++iss_kt == nk) { iss_kt = 0; if (++iss_tile < my_tiles) set_src(iss_tile); }
-        };
-        auto wait_allow = [&](int stages_in_flight) {              // 8 LDS-DMA instructions per stage per wave
-            if (stages_in_flight >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else if (stages_in_flight == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (stages_in_flight == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        set_src(0);
-        const int npre = total < PP_NS - 1 ? total : PP_NS - 1;
-        for (int g = 0; g < npre; ++g) issue();
-        wait_allow(npre - 1);
-        __builtin_amdgcn_s_barrier();                              // stage 0 published
-        for (int b = 0; b + 1 < total; ++b) {
-            int issued = b + PP_NS - 1; if (issued > total) issued = total;
-            wait_allow(issued - (b + 2));                          // stage b+1 landed; b+2, b+3 may fly
-            __builtin_amdgcn_s_barrier();                          // publishes stage b+1; stage b-1's buffer is free
-            if (b + PP_NS - 1 < total) issue();                    // stage b+4 -> buffer of stage b-1
-        }
-        return;
-    }
-
-    // ---- MFMA role
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fr = lane & 15, fg = lane >> 4;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int offA = pp_lds_off(wm * 64 + fr, fg), offB = 8192 + pp_lds_off(wn * 64 + fr, fg);   // +i*16 rows keeps the swizzle term
-    auto read_frags = [&](u32x4 (&fa)[4], u32x4 (&fb)[4], const char* buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *(const u32x4*)(buf + offA + i * 16 * 64);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(buf + offB + j * 16 * 64);
-    };
-    auto mma_all = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[4]) {        // transposed: D rows = n, cols = m
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
-    };
-    uint32_t key = 0;
-    if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
-    TO* Cp = (TO*)p.C;
-    const bool vok = p.vec_ok && (((p.ldc * sizeof(TO)) & 15) == 0) && (((uintptr_t)Cp & 15) == 0);
-
-    // Epilogue straight from the accumulators.  acc[i][j] of lane (fr, fg) is row i*16+fr, columns j*16+fg*4..+3;
-    // swapping the odd 16-lane rows of acc[i][2q] with the even rows of acc[i][2q+1] leaves each lane with 8
-    // consecutive columns starting at (2q + (fg&1))*16 + (fg>>1)*8.
-    auto epilogue = [&](int ti) {
-        const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
-        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int col = n0 + wn * 64 + (2 * q + (fg & 1)) * 16 + (fg >> 1) * 8;
-            const bool full = vok && (col + 7 < p.N);
-            float bv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-            if (p.bias && col < p.N) {
-                if (full) {
-                    const f32x4 b0 = *(const f32x4*)(p.bias + col), b1 = *(const f32x4*)(p.bias + col + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = m0 + wm * 64 + i * 16 + fr;
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = acc[i][2 * q][e], y = acc[i][2 * q + 1][e];
-                    // (inline asm: the clang builtin folded the four per-element swaps of a quad into one)
-                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
-                    v[e] = x;
-                    v[4 + e] = y;
-                }
-                acc[i][2 * q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc[i][2 * q + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (row >= p.M || col >= p.N) continue;
-                if (p.dbg >= 3 && v[0] != 12345.678f) continue;      // ablation: no stores
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bv[e];
-                if (p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (p.relu_mask) {
-                    const bf16_t* mp = (const bf16_t*)p.relu_mask + (int64_t)row * p.ldmask + col;
-                    if (full && p.mask_vec_ok) {
-                        const bf16x4 m0v = *(const bf16x4*)mp, m1v = *(const bf16x4*)(mp + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = (float)m0v[e] > 0.f ? v[e] : 0.f;
-                            v[4 + e] = (float)m1v[e] > 0.f ? v[4 + e] : 0.f;
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (col + e < p.N) v[e] = (float)mp[e] > 0.f ? v[e] : 0.f;
-                    }
-                }
-                if (p.drop) {
-                    const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
-                }
-                if (p.residual) {
-                    const float* rp = p.residual + (int64_t)row * p.ldr + col;
-                    if (full) {
-                        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (col + e < p.N) v[e] += rp[e];
-                    }
-                }
-                TO* cp = Cp + (int64_t)row * p.ldc + col;
-                if (full) {
-                    if constexpr (sizeof(TO) == 4) {
-                        *(f32x4*)cp = (f32x4){v[0], v[1], v[2], v[3]};
-                        *(f32x4*)(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                    } else {
-                        bf16x8 o;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-                        *(bf16x8*)cp = o;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (col + e < p.N) cp[e] = from_f32<TO>(v[e]);
-                }
-            }
-        }
-    };
-
-    u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
-    __builtin_amdgcn_s_barrier();                                  // stage 0 published by the loaders
-    read_frags(fa0, fb0, lds);
-    int kt = 0, tile_i = 0, buf_i = 0;
-    // two K steps per trip so the fragment double buffer needs no register copies
-    for (int g = 0; g < total; g += 2) {
-        {
-            int nb = buf_i + 1; if (nb == PP_NS) nb = 0;
-            if (g + 1 < total) {
-                __builtin_amdgcn_s_barrier();                      // stage g+1 visible (stage g-1's buffer goes back to the loaders)
-                read_frags(fa1, fb1, lds + nb * PP_STAGE);
-            }
-            mma_all(fa0, fb0);
-            buf_i = nb;
-            if (++kt == nk) { epilogue(tile_i); kt = 0; ++tile_i; }
-        }
-        if (g + 1 < total) {
-            int nb = buf_i + 1; if (nb == PP_NS) nb = 0;
-            if (g + 2 < total) {
-                __builtin_amdgcn_s_barrier();
-                read_frags(fa0, fb0, lds + nb * PP_STAGE);
-            }
-            mma_all(fa1, fb1);
-            buf_i = nb;
-            if (++kt == nk) { epilogue(tile_i); kt = 0; ++tile_i; }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Persistent form of the LDS-DMA kernel: one workgroup per CU walks its tiles with ONE continuous
-// stage pipeline -- the first stages of the next tile are already in flight while the current tile
-// finishes, so the per-tile prologue (HBM/L2 latency), epilogue and workgroup dispatch no longer
-// serialise (they dominated at K = 384: six K steps per tile).  The accumulators are kept
-// TRANSPOSED (mfma(B, A)): a lane then owns 4 consecutive output columns of one row, so the
-// epilogue stores 8/16-byte pieces straight from registers and needs no LDS staging at all.
-template <typename TO>
-__global__ __launch_bounds__(512) void gemm_nt_pers_kernel(NtParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE + 8 * 4096];   // 4 stages + a 4 KB epilogue slice per wave = 160 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int G = gridDim.x;
-    const int my_tiles = (p.n_tiles - (int)blockIdx.x + G - 1) / G;
-    const int nk = p.K / 64;
-    const int total = my_tiles * nk;
-
-    const int prow = lane >> 3, slot = lane & 7;
-    const int chunk = slot ^ prow;
-    const char* srcA[2];
-    const char* srcB[2];
-    auto set_src = [&](int ti) {
-        const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
-        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (2 * wave + i) * 8 + prow;
-            int gm = m0 + row; if (gm > p.M - 1) gm = p.M - 1;
-            int gn = n0 + row; if (gn > p.N - 1) gn = p.N - 1;
-            srcA[i] = p.A + (int64_t)gm * p.lda_b + chunk * 16;
-            srcB[i] = p.B + (int64_t)gn * p.ldb_b + chunk * 16;
-        }
-    };
-    int iss_tile = 0, iss_kt = 0;
-    set_src(0);
-    auto issue = [&](int g) {
-        char* base = lds + (g & (GL_NST - 1)) * GL_STAGE + (2 * wave) * 1024;
-        const int64_t koff = (int64_t)iss_kt * 128;
-        if ((p.dbg != 1 && p.dbg != 4) || g == 0) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[0] + koff), (lptr_t)(base), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[1] + koff), (lptr_t)(base + 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcB[0] + koff), (lptr_t)(base + 16384), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcB[1] + koff), (lptr_t)(base + 16384 + 1024), 16, 0, 0);
-        }
-        if (++iss_kt == nk) { iss_kt = 0; if (++iss_tile < my_tiles) set_src(iss_tile); }
-    };
-
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fg = lane >> 4;
-    auto read_frags = [&](u32x4 (&fa)[2], u32x4 (&fb)[4], const char* buf, int ks) {
-        const int ka = nt_lds_off(wm * 32 + fr, ks * 4 + fg), kb = nt_lds_off(wn * 64 + fr, ks * 4 + fg);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(buf + ka + i * 16 * 128);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(buf + 16384 + kb + j * 16 * 128);
-    };
-    auto mma_all = [&](const u32x4 (&fa)[2], const u32x4 (&fb)[4]) {      // transposed: D rows = n, cols = m
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
-    };
-    uint32_t key = 0;
-    if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
-    TO* Cp = (TO*)p.C;
-    // Epilogue: the transposed accumulators (lane = row fr, 4 consecutive columns per (i,j)) are
-    // passed through a wave-private 16 x 64 fp32 LDS slice (XOR-swizzled 16-byte chunks) and read
-    // back by rows, so one store instruction covers 4 whole rows (4-8 full cache lines) instead of
-    // 16 partial ones -- the stores were transaction-bound, not byte-bound.
-    float* stage = (float*)(lds + GL_NST * GL_STAGE + wave * 4096);
-    auto epilogue = [&](int ti) -> bool {
-        const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
-        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-        const bool interior = p.vec_ok && (m0 + BM <= p.M) && (n0 + BN <= p.N) && p.dbg == 0;
-        const int ch = lane & 15;                              // 16-byte chunk = 4 columns
-        const int col = n0 + wn * 64 + ch * 4;
-        const bool full = p.vec_ok && (col + 3 < p.N);
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && col < p.N) {
-            if (full) bv = *(const f32x4*)(p.bias + col);
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *(f32x4*)(stage + fr * 64 + (((j * 4 + fg) ^ fr) << 2)) = acc[i][j];
-                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int lrow = it * 4 + (lane >> 4);
-                const int row = m0 + wm * 32 + i * 16 + lrow;
-                f32x4 v = *(const f32x4*)(stage + lrow * 64 + ((ch ^ lrow) << 2));
-                if (row >= p.M || col >= p.N) continue;
-                if (p.dbg >= 3 && v[0] != 12345.678f) continue;      // ablation: no stores
-                v += bv;
-                if (p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (p.relu_mask) {
-                    const bf16_t* mp = (const bf16_t*)p.relu_mask + (int64_t)row * p.ldmask + col;
-                    if (full && p.mask_vec_ok) {
-                        const bf16x4 mk = *(const bf16x4*)mp;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (col + e < p.N) v[e] = (float)mp[e] > 0.f ? v[e] : 0.f;
-                    }
-                }
-                if (p.drop) {
-                    const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
-                }
-                if (p.residual) {
-                    const float* rp = p.residual + (int64_t)row * p.ldr + col;
-                    if (full) v += *(const f32x4*)rp;
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (col + e < p.N) v[e] += rp[e];
-                    }
-                }
-                TO* cp = Cp + (int64_t)row * p.ldc + col;
-                if (full) {
-                    if (sizeof(TO) == 4) *(f32x4*)cp = v;
-                    else {
-                        bf16x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-                        *(bf16x4*)cp = o;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (col + e < p.N) cp[e] = from_f32<TO>(v[e]);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        return interior;
-    };
-
-    int nstamp = 0;
-    auto stamp = [&]() {
-        if (p.stamps && tid == 0 && nstamp < 64) p.stamps[(size_t)blockIdx.x * 64 + nstamp] = __builtin_amdgcn_s_memtime();
-        ++nstamp;
-    };
-    stamp();
-    const int npre = total < GL_NST - 1 ? total : GL_NST - 1;
-    for (int g = 0; g < npre; ++g) issue(g);
-    u32x4 fa0[2], fb0[4], fa1[2], fb1[4];
-    if (npre >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (npre == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    read_frags(fa0, fb0, lds, 0);
-    stamp();
-    int kt = 0, tile_i = 0, relaxed = 0;
-    for (int g = 0; g < total; ++g) {
-        const char* buf = lds + (g & (GL_NST - 1)) * GL_STAGE;
-        if (p.dbg != 2) { read_frags(fa1, fb1, buf, 1); mma_all(fa0, fb0); }
-        if (g + 1 < total) {
-            int issued = g + GL_NST - 1; if (issued > total) issued = total;
-            // vmcnt counts every VMEM op in order, so "all but the 4 youngest" always covers stage g+1
-            // ... and stores count too: for two hand-overs after an interior tile's epilogue its 8 store
-            // instructions are younger than the stage being waited for and may stay in flight (waiting
-            // for their write acknowledgements cost ~2 us per tile)
-            if (issued - (g + 2) >= 1) {
-                if (relaxed > 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else if (relaxed > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (relaxed > 0) --relaxed;
-            __builtin_amdgcn_s_barrier();
-            if (g + GL_NST - 1 < total) issue(g + GL_NST - 1);
-            if (p.dbg != 2) read_frags(fa0, fb0, lds + ((g + 1) & (GL_NST - 1)) * GL_STAGE, 0);
-        }
-        if (p.dbg != 2) mma_all(fa1, fb1);
-        stamp();
-        if (++kt == nk) { relaxed = epilogue(tile_i) ? 2 : 0; kt = 0; ++tile_i; stamp(); }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// EXPERIMENT (DG_GEMM_NT=5 only; not used by default): 256 x 128 tile, 32-deep K steps, six 24 KB stages --
-// 25 % fewer operand bytes per FLOP than the 128 x 128 kernel, same wave specialisation.  Measured on the
-// training shapes it is 7-16 % SLOWER than the 128 x 128 kernel (QKV 35.0 vs 30.1 us, FFN1 41.5 vs 36.3) and
-// only 4 % faster at 4096^3: twice the barriers per 64 of K and half the workgroup rounds cost more than the
-// saved fill bytes.  Kept as the measured negative it is.
-// waves 0-7 = 4 x 2 MFMA waves of 64 x 64 (one v_mfma_f32_16x16x32_bf16 per 16 x 16 block and stage),
-// waves 8-11 = loaders, up to five stages (120 KB) in flight.  LDS rows are 64 B (4 chunks); chunk position
-// = chunk ^ (2 * ((row >> 3) & 1)), conflict-free for the 16-row x 2-chunk ds_read_b128 groups.  The epilogue
-// stores the transposed accumulators straight from registers (measured: the store shape does not matter).
-#define W2_NST 6
-#define W2_STAGE 24576                        // A 256 rows x 64 B + B 128 rows x 64 B
-__device__ __forceinline__ int w2_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) << 1)) << 4); }
-
-template <typename TO>
-__global__ __launch_bounds__(768) void gemm_nt_ws2_kernel(NtParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[W2_NST * W2_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G = gridDim.x;
-    const int tiles_n = p.tiles_n;                              // 128-wide
-    const int tiles_m2 = (p.M + 255) / 256;
-    const int n_tiles2 = tiles_m2 * tiles_n;
-    const int my_tiles = (n_tiles2 - (int)blockIdx.x + G - 1) / G;
-    const int nk = p.K / 32;
-    const int total = my_tiles * nk;
-    auto tile_origin = [&](int ti, int& m0, int& n0) {
-        const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, n_tiles2);
-        m0 = (tile / tiles_n) * 256; n0 = (tile % tiles_n) * 128;
-    };
-    if (wave >= 8) {
-        // ------------------------------------------------------------------ loaders
-        const int lw = wave - 8;
-        const int prow = lane >> 2, slot = lane & 3;
-        const int chunk = slot ^ (((prow >> 3) & 1) << 1);
-        const char* srcA[4];
-        const char* srcB[2];
-        auto set_src = [&](int ti) {
-            int m0, n0;
-            tile_origin(ti, m0, n0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int gm = m0 + (4 * lw + i) * 16 + prow; if (gm > p.M - 1) gm = p.M - 1;
-                srcA[i] = p.A + (int64_t)gm * p.lda_b + chunk * 16;
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int gn = n0 + (2 * lw + i) * 16 + prow; if (gn > p.N - 1) gn = p.N - 1;
-                srcB[i] = p.B + (int64_t)gn * p.ldb_b + chunk * 16;
-            }
-        };
-        int iss_tile = 0, iss_kt = 0;
-        auto issue = [&](int g) {
-            char* base = lds + (g % W2_NST) * W2_STAGE;
-            const int64_t koff = (int64_t)iss_kt * 64;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + koff), (lptr_t)(base + (4 * lw + i) * 1024), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + koff), (lptr_t)(base + 16384 + (2 * lw + i) * 1024), 16, 0, 0);
-            if (++iss_kt == nk) { iss_kt = 0; if (++iss_tile < my_tiles) set_src(iss_tile); }
-        };
-        auto wait_ahead = [&](int ahead) {                       // `ahead` younger stages (6 pieces each) may stay in flight
-            if (ahead >= 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else if (ahead == 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        set_src(0);
-        const int npre = total < W2_NST - 1 ? total : W2_NST - 1;
-        for (int g = 0; g < npre; ++g) issue(g);
-        wait_ahead(npre - 1);
-        __builtin_amdgcn_s_barrier();                              // stage 0 published
-        for (int g = 0; g + 1 < total; ++g) {
-            int issued = g + W2_NST - 1; if (issued > total) issued = total;
-            wait_ahead(issued - (g + 2));
-            __builtin_amdgcn_s_barrier();                          // publishes stage g+1; stage g-1's buffer is free
-            if (g + W2_NST - 1 < total) issue(g + W2_NST - 1);
-        }
-        return;
-    }
-    // ---------------------------------------------------------------------- MFMA waves
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fr = lane & 15, fg = lane >> 4;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int offA = w2_off(wm * 64 + fr, fg), offB = 16384 + w2_off(wn * 64 + fr, fg);     // +16 rows keep the swizzle
-    auto read_frags = [&](u32x4 (&fa)[4], u32x4 (&fb)[4], int g) {
-        const char* buf = lds + (g % W2_NST) * W2_STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *(const u32x4*)(buf + offA + i * 16 * 64);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(buf + offB + j * 16 * 64);
-    };
-    auto mma_all = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[4]) {      // transposed: D rows = n, cols = m
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
-    };
-    uint32_t key = 0;
-    if (p.drop) key = dg_site_key_dev(p.rng_state, p.site);
-    TO* Cp = (TO*)p.C;
-    auto epilogue = [&](int ti) {
-        int m0, n0;
-        tile_origin(ti, m0, n0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wn * 64 + j * 16 + 4 * fg;
-            const bool full = p.vec_ok && (col + 3 < p.N);
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && col < p.N) {
-                if (full) bv = *(const f32x4*)(p.bias + col);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = m0 + wm * 64 + i * 16 + fr;
-                f32x4 v = acc[i][j] + bv;
-                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (row >= p.M || col >= p.N) continue;
-                if (p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (p.relu_mask) {
-                    const bf16_t* mp = (const bf16_t*)p.relu_mask + (int64_t)row * p.ldmask + col;
-                    if (full && p.mask_vec_ok) {
-                        const bf16x4 mk = *(const bf16x4*)mp;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (float)mk[e] > 0.f ? v[e] : 0.f;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (col + e < p.N) v[e] = (float)mp[e] > 0.f ? v[e] : 0.f;
-                    }
-                }
-                if (p.drop) {
-                    const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
-                }
-                if (p.residual) {
-                    const float* rp = p.residual + (int64_t)row * p.ldr + col;
-                    if (full) v += *(const f32x4*)rp;
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (col + e < p.N) v[e] += rp[e];
-                    }
-                }
-                TO* cp = Cp + (int64_t)row * p.ldc + col;
-                if (full) {
-                    if (sizeof(TO) == 4) *(f32x4*)cp = v;
-                    else {
-                        bf16x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-                        *(bf16x4*)cp = o;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (col + e < p.N) cp[e] = from_f32<TO>(v[e]);
-                }
-            }
-        }
-    };
-    u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
-    __builtin_amdgcn_s_barrier();                                  // stage 0 published by the loaders
-    read_frags(fa0, fb0, 0);
-    int kt = 0, tile_i = 0;
-    for (int g = 0; g < total; g += 2) {                           // total is even (K % 64 == 0)
-        __builtin_amdgcn_s_barrier();                              // stage g+1 visible
-        read_frags(fa1, fb1, g + 1);
-        mma_all(fa0, fb0);
-        if (g + 2 < total) {
-            __builtin_amdgcn_s_barrier();                          // stage g+2 visible
-            read_frags(fa0, fb0, g + 2);
-        }
-        mma_all(fa1, fb1);
-        kt += 2;
-        if (kt == nk) { epilogue(tile_i); kt = 0; ++tile_i; }
-    }
-}
-
 static unsigned long long* g_stamp_buffer = nullptr;
 // diagnostic only (tools/gemm_stamps.py): not part of the public header
 extern "C" void dg_debug_set_stamp_buffer(void* p) { g_stamp_buffer = (unsigned long long*)p; }
-extern "C" int dg_debug_pp_occupancy() {      // workgroups of the paired kernel the runtime will co-schedule on one CU
-    int n = -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_nt_pp_kernel<bf16_t>, 384, 0) != hipSuccess) return -1;
-    return n;
-}
 
-// bf16 NT variant switch for A/B benchmarking: DG_GEMM_NT = 0 wave-specialised persistent LDS-DMA (default),
-// 1 register-staged, 2 LDS-DMA one tile per workgroup, 4 persistent LDS-DMA without loader waves, 5 the 256 x 128 experiment,
-// 6 the paired-workgroup experiment
+// bf16 NT variant switch for A/B benchmarking: DG_GEMM_NT = 0 wave-specialised persistent LDS-DMA (default), 1 register-staged
 static int dg_nt_mode() {
     static const int v = [] { const char* e = getenv("DG_GEMM_NT"); return e ? atoi(e) : 0; }();
     return v;
@@ -1396,21 +671,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
     p.n_tiles = tiles_m * p.tiles_n;
     dim3 grid(p.n_tiles), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 4) {
-        dim3 pgrid(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
-        if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_pers_kernel<bf16_t>), pgrid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((gemm_nt_pers_kernel<float>), pgrid, dim3(512), 0, s, p);
-    } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 5) {
-        const int n2 = ((a->M + 255) / 256) * p.tiles_n;
-        dim3 pgrid(n2 < dg_num_cus() ? n2 : dg_num_cus());
-        if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws2_kernel<bf16_t>), pgrid, dim3(768), 0, s, p);
-        else hipLaunchKernelGGL((gemm_nt_ws2_kernel<float>), pgrid, dim3(768), 0, s, p);
-    } else if (a->in_dtype == DG_BF16 && a->K % 32 == 0 && a->K >= 64 && dg_nt_mode() == 6) {
-        const int slots = 2 * dg_num_cus();
-        dim3 pgrid(p.n_tiles < slots ? p.n_tiles : slots);
-        if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_pp_kernel<bf16_t>), pgrid, dim3(384), 0, s, p);
-        else hipLaunchKernelGGL((gemm_nt_pp_kernel<float>), pgrid, dim3(384), 0, s, p);
-    } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 0) {
+    if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 0) {
         dim3 pgrid(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
         static const int pf_mode = [] { const char* e = getenv("DG_GEMM_PF"); return e ? atoi(e) : 1; }();   // 0 = load the mask bits inside the epilogue (A/B runs)
         const bool pf = pf_mode && a->sign_bits != nullptr && p.vec_ok && (!a->bias || dg_aligned16(a->bias)) &&
@@ -1445,9 +706,6 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
             else hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, NJ_, 0>), pgrid, wsb, 0, s, p); } while (0)
         if (wide) DG_WS_LAUNCH(6); else DG_WS_LAUNCH(4);
 #undef DG_WS_LAUNCH
-    } else if (a->in_dtype == DG_BF16 && a->K % 64 == 0 && a->K >= 128 && dg_nt_mode() == 2) {
-        if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_glds_kernel<bf16_t>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((gemm_nt_glds_kernel<float>), grid, dim3(512), 0, s, p);
     } else if (a->in_dtype == DG_BF16 && a->out_dtype == DG_BF16)
         hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, block, 0, s, p);
     else if (a->in_dtype == DG_BF16)
@@ -1582,108 +840,6 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnParams p) {
                 const int row = p0 + wp * 64 + i * 16 + fg * 4 + r;
                 if (row < p.P) out[(int64_t)row * p.ldo + col] = acc[i][j][r];
             }
-    }
-}
-
-// ---- bf16, LDS-DMA form: 8 waves (4 x 2 of 32 x 64), 4 stages of [64 r][128 cols] x 2 operands,
-//      global_load_lds writes image (b) directly (per-lane SOURCE chunk = slot ^ f(row)), counted
-//      vmcnt + one raw barrier per K step, fragments of the next half step always in flight.
-//      Requires whole 64-row steps (R % 64 == 0); column tails read clamped (finite) data that only
-//      reaches outputs which are not stored.  Accumulators transposed (mfma(B, A)): 16-byte stores.
-__global__ __launch_bounds__(512) void gemm_tn_glds_kernel(TnParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wp = wave >> 1, wq = wave & 1;
-    int tile, split;
-    tn_work(p, tile, split);
-    if (tile >= p.n_tiles) return;                          // padding of the 1-D grid (whole workgroup)
-    const int p0 = (tile / p.tiles_q) * 128, q0 = (tile % p.tiles_q) * 128;
-    const int r_begin = split * p.r_per_split;
-    int r_end = r_begin + p.r_per_split; if (r_end > p.R) r_end = p.R;
-    const int nk = r_end > r_begin ? (r_end - r_begin) / 64 : 0;
-
-    // piece = 1 KB = 4 rows x 256 B; this wave moves pieces 2w, 2w+1 of A and of B per stage
-    const int prow = lane >> 4, slot = lane & 15;
-    const char* srcA[2];
-    const char* srcB[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = 2 * wave + i;
-        const int row = 4 * q + prow;
-        const int chunk = slot ^ ((prow << 2) | (q & 3));           // f(row) of image (b): ((row&3)<<2)|((row>>2)&3)
-        int ca = p0 + chunk * 8; if (ca + 8 > p.lda_b / 2) ca = 0;   // past the leading dimension: clamp
-        int cb = q0 + chunk * 8; if (cb + 8 > p.ldb_b / 2) cb = 0;
-        srcA[i] = p.A + (int64_t)(r_begin + row) * p.lda_b + (int64_t)ca * 2;
-        srcB[i] = p.B + (int64_t)(r_begin + row) * p.ldb_b + (int64_t)cb * 2;
-    }
-    auto issue = [&](int kt) {
-        char* base = lds + (kt & (GL_NST - 1)) * GL_STAGE + (2 * wave) * 1024;
-        const int64_t ra = (int64_t)kt * 64 * p.lda_b, rb = (int64_t)kt * 64 * p.ldb_b;
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[0] + ra), (lptr_t)(base), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[1] + ra), (lptr_t)(base + 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcB[0] + rb), (lptr_t)(base + 16384), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcB[1] + rb), (lptr_t)(base + 16384 + 1024), 16, 0, 0);
-    };
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int fr = lane & 15, fg = lane >> 4;
-    auto read_frags = [&](u32x4 (&fa)[2], u32x4 (&fb)[4], const char* buf, int ks) {
-        const int r0 = ks * 32 + fg * 8;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = tn_frag_bf16(buf, r0, wp * 32 + i * 16, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = tn_frag_bf16(buf + 16384, r0, wq * 64 + j * 16, lane);
-    };
-    auto mma_all = [&](const u32x4 (&fa)[2], const u32x4 (&fb)[4]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
-    };
-    if (nk > 0) {
-        const int npre = nk < GL_NST - 1 ? nk : GL_NST - 1;
-        for (int g = 0; g < npre; ++g) issue(g);
-        u32x4 fa0[2], fb0[4], fa1[2], fb1[4];
-        if (npre >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (npre == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        read_frags(fa0, fb0, lds, 0);
-        for (int g = 0; g < nk; ++g) {
-            const char* buf = lds + (g & (GL_NST - 1)) * GL_STAGE;
-            read_frags(fa1, fb1, buf, 1);
-            mma_all(fa0, fb0);
-            if (g + 1 < nk) {
-                int issued = g + GL_NST - 1; if (issued > nk) issued = nk;
-                if (issued - (g + 2) >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (g + GL_NST - 1 < nk) issue(g + GL_NST - 1);
-                read_frags(fa0, fb0, lds + ((g + 1) & (GL_NST - 1)) * GL_STAGE, 0);
-            }
-            mma_all(fa1, fb1);
-        }
-    }
-    float* out = p.out + (int64_t)split * p.split_stride;
-    const bool vec = (p.ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = p0 + wp * 32 + i * 16 + fr;
-        if (row >= p.P) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = q0 + wq * 64 + j * 16 + 4 * fg;
-            float* op = out + (int64_t)row * p.ldo + col;
-            if (vec && col + 3 < p.Q) *(f32x4*)op = acc[i][j];
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < p.Q) op[e] = acc[i][j][e];
-            }
-        }
     }
 }
 
@@ -2293,8 +1449,6 @@ extern "C" int dg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
     const bool one_round = (int64_t)p.n_tiles * n_splits <= dg_num_cus();
     if (dtype == DG_BF16 && R % 64 == 0 && (tn_mode == 3 || (tn_mode == 0 && one_round)))
         hipLaunchKernelGGL(gemm_tn_ws_kernel, grid, dim3(768), 0, s, p);
-    else if (dtype == DG_BF16 && R % 64 == 0 && tn_mode == 2)
-        hipLaunchKernelGGL(gemm_tn_glds_kernel, grid, dim3(512), 0, s, p);
     else if (dtype == DG_BF16) hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, block, 0, s, p);
     else hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, block, 0, s, p);
     DG_LAUNCH_CHECK();
