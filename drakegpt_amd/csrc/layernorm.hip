@@ -8,7 +8,7 @@
 // LN_MAXV (template): float4 per lane kept in registers; C <= 256*LN_MAXV on the fast path
 #define LN_MAXV_CAP 8
 
-#define LN_RPW 4      // rows per wave, loaded together: the forward kernel is latency-bound, not byte-bound
+#define LN_RPW 2      // rows per wave, loaded together (inside the step 2 beats 1, 4 and 8: lighter waves, more of them)
 template <typename TO, bool VEC, int LN_MAXV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                               const float* __restrict__ beta, TO* __restrict__ y,
