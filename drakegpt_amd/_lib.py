@@ -57,7 +57,7 @@ SIGNATURES = {
     "dg_version": [],
     "dg_state_advance": [_vp, _vp],
     "dg_batch_gather": [_vp, _i64, _vp, _vp, _vp, _i, _i, _vp],
-    "dg_embed_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "dg_embed_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp],
     "dg_embed_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "dg_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp],
     "dg_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],

@@ -45,7 +45,7 @@ extern "C" int dg_batch_gather(const int64_t* corpus, int64_t n_corpus, const in
 template <int VEC>
 __global__ void embed_fwd_kernel(const int64_t* __restrict__ idx, const float* __restrict__ tok,
                                  const float* __restrict__ pos, float* __restrict__ x,
-                                 int64_t M, int T, int C, int V) {
+                                 int64_t M, int T, int C, int V, bf16_t* __restrict__ onehot, int64_t ld_onehot) {
     const int cv = C / VEC;
     int64_t total = M * cv;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -55,6 +55,17 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ idx, const float* _
         int64_t v = idx[m];
         v = v < 0 ? 0 : (v >= V ? V - 1 : v);
         int t = (int)(m % T);
+        if (onehot) {
+            // row m of the one-hot matrix, 8 columns per (m, c) work item: the dY^T X operand that turns the token-table
+            // gradient into one more problem of the grouped dW GEMM (no atomics, no scatter)
+            const int j = (int)(i % cv);
+            if (VEC == 4 && j * 8 < ld_onehot) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((int64_t)(j * 8 + e) == v ? 1.f : 0.f);
+                *(bf16x8*)(onehot + m * ld_onehot + j * 8) = o;
+            }
+        }
         if (VEC == 4) {
             f32x4 a = *(const f32x4*)(tok + v * C + c);
             if (pos) a += *(const f32x4*)(pos + (int64_t)t * C + c);
@@ -68,17 +79,20 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ idx, const float* _
 }
 
 extern "C" int dg_embed_fwd(const int64_t* idx, const float* tok, const float* pos, float* x,
-                            int B, int T, int C, int V, void* stream) {
+                            int B, int T, int C, int V, void* onehot, int64_t ld_onehot, void* stream) {
     if (!idx || !tok || !x || B <= 0 || T <= 0 || C <= 0 || V <= 0) return DG_ERR_ARG;
+    if (onehot && (C % 4 || ld_onehot % 8 || ld_onehot < V || (int64_t)(C / 4) * 8 < ld_onehot || !dg_aligned16(onehot))) return DG_ERR_ARG;
     int64_t M = (int64_t)B * T;
     bool vec = (C % 4 == 0) && dg_aligned16(tok) && dg_aligned16(x) && (!pos || dg_aligned16(pos));
     int64_t total = vec ? M * (C / 4) : M * C;
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
     if (vec)
-        hipLaunchKernelGGL(embed_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, tok, pos, x, M, T, C, V);
-    else
-        hipLaunchKernelGGL(embed_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, tok, pos, x, M, T, C, V);
+        hipLaunchKernelGGL(embed_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, tok, pos, x, M, T, C, V, (bf16_t*)onehot, ld_onehot);
+    else {
+        if (onehot) return DG_ERR_ALIGN;
+        hipLaunchKernelGGL(embed_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, tok, pos, x, M, T, C, V, (bf16_t*)nullptr, (int64_t)0);
+    }
     DG_LAUNCH_CHECK();
     return DG_OK;
 }
@@ -110,16 +124,18 @@ __global__ void embed_bwd_pos_kernel(const float* __restrict__ dx, float* __rest
 
 extern "C" int dg_embed_bwd(const int64_t* idx, const float* dx, float* dtok, float* dpos,
                             int B, int T, int C, int V, void* stream) {
-    if (!idx || !dx || !dtok || B <= 0 || T <= 0 || C <= 0 || V <= 0) return DG_ERR_ARG;
+    if (!idx || !dx || (!dtok && !dpos) || B <= 0 || T <= 0 || C <= 0 || V <= 0) return DG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int64_t M = (int64_t)B * T;
-    hipError_t e = hipMemsetAsync(dtok, 0, (size_t)V * C * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
-    int64_t total = M * C;
-    unsigned grid = (unsigned)((total + 255) / 256);
-    if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3(grid), dim3(256), 0, s, idx, dx, dtok, M, C, V);
-    DG_LAUNCH_CHECK();
+    if (dtok) {
+        hipError_t e = hipMemsetAsync(dtok, 0, (size_t)V * C * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+        int64_t total = M * C;
+        unsigned grid = (unsigned)((total + 255) / 256);
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3(grid), dim3(256), 0, s, idx, dx, dtok, M, C, V);
+        DG_LAUNCH_CHECK();
+    }
     if (dpos) {
         int64_t tc = (int64_t)T * C;
         hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, s, dx, dpos, B, T, C);

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
         };
         combine(dg, dgamma_part);
         combine(db, dbeta_part);
-        if (FUSE_G) combine(gb, fz.gbias_part);
+        if (FUSE_G && fz.gbias_part) combine(gb, fz.gbias_part);       // (uniform)
     } else {
         // generic path: any C; column partials accumulate directly in LDS [2][NW][C] per wave
         float* lg = lds; float* lb = lds + NW * C;
@@ -273,7 +273,7 @@ static int ln_bwd_launch(LnFuse fz, int fuse, const void* dy, int dy_dtype, cons
     bool vec = (C % 4 == 0) && (C <= 64 * 4 * LN_MAXV_CAP) && dg_aligned16(dy) && dg_aligned16(x) && dg_aligned16(gamma) &&
                dg_aligned16(dx) && (!dresid || dg_aligned16(dresid));
     const int nk = (C / 4 + 63) / 64;
-    if (fuse && (!vec || nk > 4 || !fz.g || !fz.gbias_part || !dg_aligned16(fz.g))) return DG_ERR_ARG;
+    if (fuse && (!vec || nk > 4 || !fz.g || !dg_aligned16(fz.g))) return DG_ERR_ARG;
     if (dy_dtype == DG_BF16 && !vec) return DG_ERR_ARG;         // bf16 gradients only on the vector path
     // more waves per workgroup = more rows in flight per partial (HBM-bound: needs the occupancy)
     int nthreads = C <= 512 ? 1024 : (C <= 1024 ? 512 : 256);

@@ -75,9 +75,9 @@ class FlatSink:
     def defer(self, key, dy, x, P, Q) -> bool:
         if not self.e.grouped_dw:
             return False
-        off, shape = self.e.layA.entries[key]
+        off, shape = self.e._region(key)              # GEMM weights, or the token table (one-hot dY)
         assert shape == (P, Q), (key, shape, P, Q)
-        self.deferred.append((dy, x, self.e.gflat[self.e.offA + off:self.e.offA + off + P * Q], P, Q))
+        self.deferred.append((dy, x, self.e.gflat[off:off + P * Q], P, Q))
         return True
 
     def flush(self):
@@ -203,6 +203,10 @@ class TrainEngine:
         self.m_ = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
         self.v_ = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
         self.tn_workspace = None
+        # one-hot rows of the batch (bf16 [M, V rounded up to 8]): rewritten by every forward, read by the grouped dW GEMM
+        self.onehot = None
+        if self.grouped_dw and ops.layernorm_bwd_fused_supported(self.C) and (self.C // 4) * 8 >= S.pad_to(self.V, 8):
+            self.onehot = torch.zeros((self.M, S.pad_to(self.V, 8)), dtype=torch.bfloat16, device=dev)
         self.slabs = None if self.grouped_dw else torch.zeros((self.S, self.layA.size), dtype=torch.float32, device=dev)
         self.vparts = torch.zeros((self.G, self.layB.size), dtype=torch.float32, device=dev)
         NH, H = self.NH, self.H
@@ -275,7 +279,9 @@ class TrainEngine:
         B, T = x_idx.shape
         M = B * T
         p = self.p_drop
-        h = ops.embed_fwd(x_idx, self.param_view("tok"), self.param_view("pos")).view(M, self.C)
+        # backward gets the token-table gradient as one more problem of the grouped dW GEMM: one-hot(idx)^T dx
+        onehot = self.onehot if (want_grad and self.onehot is not None and M == self.M) else None
+        h = ops.embed_fwd(x_idx, self.param_view("tok"), self.param_view("pos"), onehot=onehot).view(M, self.C)
         saved = []
         for l in range(self.L):
             P = self._layer_params(l)
@@ -310,11 +316,20 @@ class TrainEngine:
                 dh, g_next = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink,
                                         {"wqkv": f"{l}.wqkv", "wproj": f"{l}.wproj", "bproj": f"{l}.bproj", "ln_w": f"{l}.ln1w", "ln_b": f"{l}.ln1b"},
                                         g_in=g_next, emit=emit)
+            elif self.onehot is not None:
+                # first block: also take dx in bf16 (no dropout, no bias behind it) -- the X operand of the token-table problem
+                dh, g0 = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink,
+                                    {"wqkv": f"{l}.wqkv", "wproj": f"{l}.wproj", "bproj": f"{l}.bproj", "ln_w": f"{l}.ln1w", "ln_b": f"{l}.ln1b"},
+                                    g_in=g_next, emit=(0.0, 0, None, self.C))
             else:
                 dh = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink,
                                 {"wqkv": f"{l}.wqkv", "wproj": f"{l}.wproj", "bproj": f"{l}.bproj", "ln_w": f"{l}.ln1w", "ln_b": f"{l}.ln1b"},
                                 g_in=g_next)
-        ops.embed_bwd(x_idx, dh.view(B, T, self.C), self.grad_view("tok"), self.grad_view("pos")[:T])
+        if self.onehot is not None:
+            sink.defer("tok", self.onehot[:, :self.V], g0, self.V, self.C)
+            ops.embed_bwd(x_idx, dh.view(B, T, self.C), None, self.grad_view("pos")[:T], V=self.V)
+        else:
+            ops.embed_bwd(x_idx, dh.view(B, T, self.C), self.grad_view("tok"), self.grad_view("pos")[:T])
         if self.grouped_dw:
             sink.flush()
         else:

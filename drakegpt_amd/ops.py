@@ -77,7 +77,9 @@ def batch_gather(corpus: Tensor, offsets: Tensor, T: int, x: Optional[Tensor] = 
     return x, y
 
 
-def embed_fwd(idx: Tensor, tok: Tensor, pos: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
+def embed_fwd(idx: Tensor, tok: Tensor, pos: Optional[Tensor], out: Optional[Tensor] = None,
+              onehot: Optional[Tensor] = None) -> Tensor:
+    """x = tok[idx] + pos; `onehot` (bf16 [B*T, >= V]) additionally receives one-hot rows of idx"""
     _chk(idx, "idx", torch.int64)
     _chk(tok, "tok", torch.float32)
     B, T = idx.shape
@@ -88,16 +90,22 @@ def embed_fwd(idx: Tensor, tok: Tensor, pos: Optional[Tensor], out: Optional[Ten
             raise IndexError(f"index out of range in self: sequence length {T} exceeds context_length {pos.shape[0]}")
     if out is None:
         out = torch.empty((B, T, Cd), dtype=torch.float32, device=idx.device)
-    check(lib.dg_embed_fwd(_p(idx), _p(tok), _p(pos), _p(out), B, T, Cd, V, _stream()), "dg_embed_fwd")
+    if onehot is not None:
+        _chk(onehot, "onehot", torch.bfloat16, contiguous=False)
+    check(lib.dg_embed_fwd(_p(idx), _p(tok), _p(pos), _p(out), B, T, Cd, V, _p(onehot), _ld(onehot) if onehot is not None else 0,
+                           _stream()), "dg_embed_fwd")
     return out
 
 
-def embed_bwd(idx: Tensor, dx: Tensor, dtok: Tensor, dpos: Optional[Tensor]) -> None:
+def embed_bwd(idx: Tensor, dx: Tensor, dtok: Optional[Tensor], dpos: Optional[Tensor], V: Optional[int] = None) -> None:
     _chk(idx, "idx", torch.int64)
     _chk(dx, "dx", torch.float32)
-    _chk(dtok, "dtok", torch.float32)
     B, T = idx.shape
-    V, Cd = dtok.shape
+    if dtok is not None:
+        _chk(dtok, "dtok", torch.float32)
+        V, Cd = dtok.shape
+    else:
+        Cd = dx.shape[-1]
     if dpos is not None:
         _chk(dpos, "dpos", torch.float32)
         if dpos.shape[0] != T:
@@ -137,7 +145,7 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
 
 def layernorm_bwd_fused(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dresid: Optional[Tensor],
                         dgamma_part: Tensor, dbeta_part: Tensor, part_stride: int, n_partials: int,
-                        g_dtype: torch.dtype, p: float, rng_state: Optional[Tensor], site: int, gbias_part: Tensor):
+                        g_dtype: torch.dtype, p: float, rng_state: Optional[Tensor], site: int, gbias_part: Optional[Tensor]):
     """layernorm_bwd that also emits g = dropout_bwd(dx) in g_dtype and its column-sum partials; returns (dx, g)."""
     _chk(dy, "dy")
     _chk(x, "x", torch.float32)

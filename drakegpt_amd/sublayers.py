@@ -163,7 +163,7 @@ def _ln_tail(run: Run, dh: Tensor, x2d: Tensor, ln_w: Tensor, mean, rstd, dresid
     pb, _, _ = sink.vector(keys["ln_b"], ln_w.numel())
     if emit is not None and ops.layernorm_bwd_fused_supported(ln_w.numel()):
         p, site, bias_key, N = emit
-        pq, _, _ = sink.vector(bias_key, N)
+        pq = sink.vector(bias_key, N)[0] if bias_key is not None else None       # None: g only (no sub-layer bias behind it)
         return ops.layernorm_bwd_fused(dh, x2d, ln_w, mean, rstd, dresid, pg, pb, sg, ng, run.act, run.p(p), run.rng, site, pq)
     return ops.layernorm_bwd(dh, x2d, ln_w, mean, rstd, dresid, pg, pb, sg, ng), None
 

@@ -63,8 +63,10 @@ int dg_batch_gather(const int64_t* corpus, int64_t n_corpus, const int64_t* offs
  * Returns DG_ERR_ARG if T > rows of pos is the caller's job to check; idx values are clamped
  * to [0, V) on the device (torch would raise; the Python layer checks in debug mode). */
 int dg_embed_fwd(const int64_t* idx, const float* tok, const float* pos, float* x,
-                 int B, int T, int C, int V, void* stream);
-/* Backward of the above (embedding_dense_backward).  dtok [V,C] is zero-filled here and then
+                 int B, int T, int C, int V, void* onehot, int64_t ld_onehot, void* stream);
+/* onehot (nullable): bf16 [B*T, ld_onehot >= V, multiple of 8], row m = e_{idx[m]}.  With it the token-table gradient
+ * is dg_gemm_tn_grouped problem (A = onehot, B = bf16 dx): deterministic, no atomics.
+ * Backward of the above (embedding_dense_backward).  dtok [V,C] (nullable) is zero-filled here and then
  * accumulated with fp32 atomics; dpos [T,C] (nullable) is overwritten with sum over b. */
 int dg_embed_bwd(const int64_t* idx, const float* dx, float* dtok, float* dpos,
                  int B, int T, int C, int V, void* stream);
@@ -87,7 +89,7 @@ int dg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* 
 /* The same, and additionally g[m,c] = (g_dtype)(dx[m,c] * keep/(1-p)) with its column-sum partials in
  * gbias_part (same stride / count as dgamma_part): the operand and the bias gradient that the sub-layer
  * which runs next in backward would otherwise get from dg_dropout_bwd_cast(dx, site) -- one 38 MB pass and
- * one launch less per sub-layer.  Returns DG_ERR_ARG for shapes the fused kernel does not cover
+ * one launch less per sub-layer (gbias_part may be NULL).  Returns DG_ERR_ARG for shapes the fused kernel does not cover
  * (C % 4 != 0 or C > 1024): call dg_layernorm_bwd + dg_dropout_bwd_cast then. */
 int dg_layernorm_bwd_fused(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                            const float* rstd, const float* dresid, float* dx,
