@@ -1,5 +1,7 @@
 // Fused row-wise cross entropy forward + backward (ref: F.cross_entropy at src/model.py:604-607).
-// HBM-bound: one wave64 per row; the row is read twice from L2/HBM (max+sum pass, gradient pass).
+// HBM-bound.  Small vocabularies (the reference's 80 characters): one wave64 per row, the row re-read from L2 for the
+// max, sum and gradient passes.  Large vocabularies (GPT-2's 50257: 201 KB per row, 1.65 GB of logits at M = 8192): one
+// 1024-thread workgroup per row that keeps the whole row in registers, so the logits are read from HBM exactly once.
 // Algorithmic bytes per row: V*4 read (+ V*sizeof(dlogits) written when training).
 #include "common.h"
 
@@ -33,12 +35,75 @@ __global__ void cross_entropy_kernel(const float* __restrict__ logits, int64_t l
     }
 }
 
+
+#define CE_BLOCK 1024
+#define CE_MAXK 52                    // values per thread (128-VGPR budget at 16 waves per workgroup): rows up to 53248 logits
+template <typename TD>
+__global__ __launch_bounds__(CE_BLOCK) void cross_entropy_row_kernel(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ targets,
+                                                                      float* __restrict__ loss_rows, TD* __restrict__ dlogits, int64_t ldd,
+                                                                      float grad_scale, const float* __restrict__ gs_dev, int M, int V) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row = blockIdx.x;
+    const float* x = logits + (int64_t)row * ldl;
+    float v[CE_MAXK];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < CE_MAXK; ++k) {
+        const int i = k * CE_BLOCK + tid;
+        v[k] = i < V ? x[i] : -INFINITY;
+        mx = fmaxf(mx, v[k]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mx = fmaxf(mx, red[k]);
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CE_MAXK; ++k) {
+        v[k] = expf(v[k] - mx);                          // exp(-inf) = 0 for the padding
+        s += v[k];
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    s = red[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k];             // fixed order
+    int64_t t = targets[row];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    if (tid == 0) loss_rows[row] = mx + logf(s) - x[t];
+    if (dlogits) {
+        TD* d = dlogits + (int64_t)row * ldd;
+        const float inv = 1.f / s;
+        if (gs_dev) grad_scale *= gs_dev[0];
+#pragma unroll
+        for (int k = 0; k < CE_MAXK; ++k) {
+            const int i = k * CE_BLOCK + tid;
+            if (i < (int)ldd) d[i] = from_f32<TD>(i < V ? (v[k] * inv - (i == (int)t ? 1.f : 0.f)) * grad_scale : 0.f);
+        }
+    }
+}
+
 extern "C" int dg_cross_entropy(const float* logits, int64_t ldl, const int64_t* targets, float* loss_rows,
                                 void* dlogits, int64_t ldd, int dtype, float grad_scale, const float* grad_scale_dev, int M, int V, void* stream) {
     if (!logits || !targets || !loss_rows || M <= 0 || V <= 0 || ldl < V) return DG_ERR_ARG;
     if (dlogits && ldd < V) return DG_ERR_ARG;
     dim3 grid((M + 3) / 4), block(256);
     hipStream_t s = (hipStream_t)stream;
+    const int64_t width = dlogits && ldd > V ? ldd : V;
+    if (V > 4096 && width <= (int64_t)CE_BLOCK * CE_MAXK) {
+        if (dtype == DG_BF16)
+            hipLaunchKernelGGL(cross_entropy_row_kernel<bf16_t>, dim3(M), dim3(CE_BLOCK), 0, s, logits, ldl, targets, loss_rows, (bf16_t*)dlogits, ldd, grad_scale, grad_scale_dev, M, V);
+        else if (dtype == DG_F32)
+            hipLaunchKernelGGL(cross_entropy_row_kernel<float>, dim3(M), dim3(CE_BLOCK), 0, s, logits, ldl, targets, loss_rows, (float*)dlogits, ldd, grad_scale, grad_scale_dev, M, V);
+        else return DG_ERR_DTYPE;
+        DG_LAUNCH_CHECK();
+        return DG_OK;
+    }
     if (dtype == DG_BF16)
         hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, grid, block, 0, s, logits, ldl, targets, loss_rows, (bf16_t*)dlogits, ldd, grad_scale, grad_scale_dev, M, V);
     else if (dtype == DG_F32)
