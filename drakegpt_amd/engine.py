@@ -252,7 +252,7 @@ class TrainEngine:
                 self.weights.fwd_map[W.data_ptr()] = self.shadow[self.offA + off:self.offA + off + n].view(shape)
             else:
                 self.weights.fwd_map[W.data_ptr()] = W
-            Wt = torch.zeros((shape[1], S.pad_to(shape[0], gr)), dtype=self.act, device=dev)
+            Wt = torch.zeros((shape[1], S.k_pad(shape[0], self.act)), dtype=self.act, device=dev)
             self.weights.bwd_map[W.data_ptr()] = Wt
             self._mats.append((W, Wt))
 
@@ -294,7 +294,7 @@ class TrainEngine:
             return logits, None, None
         dlogits = None
         if want_grad:
-            dlogits = torch.empty((M, S.pad_to(self.V, S.granule(self.act))), dtype=self.act, device=self.dev)
+            dlogits = torch.empty((M, S.k_pad(self.V, self.act)), dtype=self.act, device=self.dev)
         rows = ops.cross_entropy(logits, y_idx.view(M), self.V, dlogits=dlogits, grad_scale=1.0 / M)
         return logits, rows, (saved, xa, dlogits)
 

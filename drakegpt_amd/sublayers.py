@@ -44,6 +44,12 @@ def granule(dtype: torch.dtype) -> int:
     return 8 if dtype == torch.bfloat16 else 4
 
 
+def k_pad(n: int, dtype: torch.dtype) -> int:
+    """padded contraction length of a dX GEMM whose K is a Linear's out_features (lm_head: K = V): a multiple of 64 in bf16
+    so that the LDS-DMA kernel takes it (V = 80 -> 128, 50257 -> 50304), of the 16-byte granule in fp32"""
+    return pad_to(n, 64) if dtype == torch.bfloat16 else pad_to(n, granule(dtype))
+
+
 def pad_to(n: int, g: int) -> int:
     return (n + g - 1) // g * g
 
@@ -85,7 +91,7 @@ class OnTheFlyWeights:
         return ops.cast(W.contiguous(), self.act)
 
     def bwd(self, W: Tensor) -> Tensor:
-        return ops.transpose_cast(W, self.act)
+        return ops.transpose_cast(W, self.act, ldo=k_pad(W.shape[0], self.act))
 
 
 class LocalSink:
@@ -293,14 +299,17 @@ def linear_bwd_from_act(run: Run, saved, g: Tensor, w: Tensor, has_bias: bool, s
     weight_grad(sink, keys["w"], g, xa, N, K)
     if not need_dx:
         return None
-    return ops.gemm_nt(g, run.weights.bwd(w), torch.float32, K=pad_to(N, granule(run.act)))
+    wt = run.weights.bwd(w)
+    Kp = k_pad(N, run.act)
+    if ops._ld(g) < Kp or wt.shape[1] < Kp:                       # caller padded to the granule only
+        Kp = pad_to(N, granule(run.act))
+    return ops.gemm_nt(g, wt, torch.float32, K=Kp)
 
 
 def linear_bwd(run: Run, saved, dy: Tensor, w: Tensor, has_bias: bool, sink, keys, need_dx: bool = True):
     """dy fp32 [M,N] (autograd path)."""
     N = w.shape[0]
-    gr = granule(run.act)
-    Np = pad_to(N, gr)
+    Np = k_pad(N, run.act)
     M = dy.shape[0]
     part = stride = n = None
     if has_bias:
