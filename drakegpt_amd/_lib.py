@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdrakegpt_hip.so")
 
 DG_F32 = 0
 DG_BF16 = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GemmNtArgs(C.Structure):
@@ -73,7 +73,7 @@ SIGNATURES = {
     "dg_dropout_bwd_cast": [_vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp, _u32, _vp, _i64, _vp, _i64, _i, _vp],
     "dg_cast": [_vp, _i, _vp, _i, _i64, _vp],
     "dg_transpose_cast": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp],
-    "dg_transpose_cast_batched": [_vp, _i, _i, _i, _vp],
+    "dg_transpose_cast_batched": [_vp, _i, _i, _i, _i, _vp],
     "dg_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
     "dg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
     "dg_attn_bwd_workspace_bytes": [_i, _i, _i, _i, _i],

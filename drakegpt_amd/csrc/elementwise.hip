@@ -215,14 +215,14 @@ extern "C" int dg_transpose_cast(const float* in, int64_t ldi, void* out, int64_
 // many matrices in one launch (the training engine refreshes every W^T shadow after the optimizer
 // step: 4 per layer + lm_head; one launch instead of 25 keeps ~1.5 us of boundary per matrix off the
 // step).  desc (int64 x 8, device memory): {in, out, ldi, ldo, R, Cc, first_tile, tiles_x}
-template <typename TO>
+template <typename TI, typename TO>
 __global__ void transpose_cast_batched_kernel(const int64_t* __restrict__ desc, int n_desc) {
     __shared__ float tile[64][65];
     int d = 0;
     for (int i = 1; i < n_desc; ++i)
         if ((int64_t)blockIdx.x >= desc[i * 8 + 6]) d = i;
     const int64_t* D = desc + d * 8;
-    const float* in = (const float*)D[0];
+    const TI* in = (const TI*)D[0];
     TO* out = (TO*)D[1];
     const int64_t ldi = D[2], ldo = D[3];
     const int R = (int)D[4], Cc = (int)D[5];
@@ -231,7 +231,7 @@ __global__ void transpose_cast_batched_kernel(const int64_t* __restrict__ desc, 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < Cc) ? in[(int64_t)r * ldi + c] : 0.f;
+        tile[i][tx] = (r < R && c < Cc) ? to_f32<TI>(in[(int64_t)r * ldi + c]) : 0.f;
     }
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
@@ -240,12 +240,15 @@ __global__ void transpose_cast_batched_kernel(const int64_t* __restrict__ desc, 
     }
 }
 
-extern "C" int dg_transpose_cast_batched(const int64_t* desc, int n_desc, int total_tiles, int dtype, void* stream) {
+extern "C" int dg_transpose_cast_batched(const int64_t* desc, int n_desc, int total_tiles, int in_dtype, int dtype, void* stream) {
     if (!desc || n_desc <= 0 || total_tiles <= 0) return DG_ERR_ARG;
-    if (dtype == DG_BF16)
-        hipLaunchKernelGGL(transpose_cast_batched_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc, n_desc);
-    else if (dtype == DG_F32)
-        hipLaunchKernelGGL(transpose_cast_batched_kernel<float>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc, n_desc);
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == DG_F32 && dtype == DG_BF16)
+        hipLaunchKernelGGL((transpose_cast_batched_kernel<float, bf16_t>), dim3(total_tiles), dim3(256), 0, s, desc, n_desc);
+    else if (in_dtype == DG_F32 && dtype == DG_F32)
+        hipLaunchKernelGGL((transpose_cast_batched_kernel<float, float>), dim3(total_tiles), dim3(256), 0, s, desc, n_desc);
+    else if (in_dtype == DG_BF16 && dtype == DG_BF16)     // from the bf16 shadow the optimizer just wrote: half the read
+        hipLaunchKernelGGL((transpose_cast_batched_kernel<bf16_t, bf16_t>), dim3(total_tiles), dim3(256), 0, s, desc, n_desc);
     else
         return DG_ERR_DTYPE;
     DG_LAUNCH_CHECK();
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    if (c < N) {                                       // N % 8 == 0: a lane's 8 columns are all inside or all outside
+    if (c < N) {                                       // lda % 8 == 0: the 16-byte load of a ragged last chunk stays inside the row pitch
         const bf16_t* col = A + c;
         int m = m_begin + ty;
         for (; m + 28 < m_end; m += 32) {
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int cc = lane * 8 + j;
-            o[j] = red[0][cc] + red[1][cc] + red[2][cc] + red[3][cc];
+            if (c + j < N) o[j] = red[0][cc] + red[1][cc] + red[2][cc] + red[3][cc];
         }
     }
 }
@@ -395,7 +398,7 @@ extern "C" int dg_colsum(const void* A, int64_t lda, int dtype, float* part, int
     int rows_per = rows_per_partial(M, n_partials);
     dim3 grid(n_partials, (N + 255) / 256), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == DG_BF16 && N % 8 == 0 && lda % 8 == 0 && dg_aligned16(A)) {
+    if (dtype == DG_BF16 && lda % 8 == 0 && lda >= (N + 7) / 8 * 8 && dg_aligned16(A)) {
         hipLaunchKernelGGL(colsum_bf16_kernel, dim3(n_partials, (N + 511) / 512), dim3(256), 0, s, (const bf16_t*)A, lda, M, N, part,
                            part_stride, rows_per);
         DG_LAUNCH_CHECK();

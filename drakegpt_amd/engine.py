@@ -264,9 +264,12 @@ class TrainEngine:
         self._refresh_transposes()
 
     def _refresh_transposes(self):
+        # bf16: transpose the bf16 shadow the optimizer has just written (bit-identical to casting the fp32 master, half the read)
+        from_shadow = self.shadow is not None
         if getattr(self, "_tr_table", None) is None:
-            self._tr_table = ops.make_transpose_table(self._mats, self.dev)
-        ops.transpose_cast_batched(*self._tr_table, self.act)
+            pairs = [(self.weights.fwd(W) if from_shadow else W, Wt) for W, Wt in self._mats]
+            self._tr_table = ops.make_transpose_table(pairs, self.dev)
+        ops.transpose_cast_batched(*self._tr_table, self.act, in_dtype=torch.bfloat16 if from_shadow else torch.float32)
 
     # -------------------------------------------------------------------------------- programs
     def _layer_params(self, l: int):

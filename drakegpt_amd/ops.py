@@ -325,9 +325,9 @@ def make_transpose_table(pairs, device) -> tuple:
     return torch.tensor(rows, dtype=torch.int64, device=device), len(rows), first
 
 
-def transpose_cast_batched(table: Tensor, n_desc: int, total_tiles: int, dtype: torch.dtype) -> None:
+def transpose_cast_batched(table: Tensor, n_desc: int, total_tiles: int, dtype: torch.dtype, in_dtype: torch.dtype = torch.float32) -> None:
     _chk(table, "table", torch.int64)
-    check(lib.dg_transpose_cast_batched(_p(table), n_desc, total_tiles, dt_code(dtype), _stream()), "dg_transpose_cast_batched")
+    check(lib.dg_transpose_cast_batched(_p(table), n_desc, total_tiles, dt_code(in_dtype), dt_code(dtype), _stream()), "dg_transpose_cast_batched")
 
 
 def attn_fwd(qkv: Tensor, B: int, T: int, NH: int, H: int, scale: float, p: float, rng_state: Optional[Tensor], site: int):

@@ -42,7 +42,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 1
+#define DG_ABI_VERSION 2   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -190,8 +190,9 @@ int dg_transpose_cast(const float* in, int64_t ldi, void* out, int64_t ldo, int 
 
 /* The same for n_desc matrices in ONE launch.  desc: device array of n_desc x 8 int64
  * {in ptr, out ptr, ldi, ldo, R, Cc, first_tile, tiles_x} where a matrix owns tiles_x * ceil(ldo/64)
- * consecutive 64x64 tiles starting at first_tile (tiles_x = ceil(Cc/64)); total_tiles = their sum. */
-int dg_transpose_cast_batched(const int64_t* desc, int n_desc, int total_tiles, int dtype, void* stream);
+ * consecutive 64x64 tiles starting at first_tile (tiles_x = ceil(Cc/64)); total_tiles = their sum.
+ * in_dtype: DG_F32 (the fp32 masters) or, for bf16 output, DG_BF16 (the bf16 shadow copy: same values, half the read). */
+int dg_transpose_cast_batched(const int64_t* desc, int n_desc, int total_tiles, int in_dtype, int out_dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Causal multi-head attention -- ref: Head2.forward src/model_component.py:392-405 for every

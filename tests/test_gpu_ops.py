@@ -337,9 +337,10 @@ def test_casts_and_colsum(dev):
     assert rel(cs, dy.bfloat16().double().sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("M,N,G,ld", [(16384, 1536, 256, 1536), (1000, 384, 31, 392), (517, 80, 16, 80), (64, 1032, 1, 1040), (300, 84, 7, 88)])
+@pytest.mark.parametrize("M,N,G,ld", [(16384, 1536, 256, 1536), (1000, 384, 31, 392), (517, 80, 16, 80), (64, 1032, 1, 1040), (300, 84, 7, 88), (256, 50257, 8, 50304), (100, 33, 3, 35)])
 def test_colsum_bf16(dev, M, N, G, ld):
-    """the 16-byte-load kernel (N % 8 == 0) and the generic one (N = 84), ragged row chunks, padded leading dimension"""
+    """the 16-byte-load kernel (leading dimension a multiple of 8; N may be ragged: 84, 50257) and the generic one (ld = 35),
+    ragged row chunks, padded leading dimension"""
     ops = _ops()
     g = torch.Generator().manual_seed(M + N)
     A = torch.zeros(M, ld, dtype=torch.bfloat16)
