@@ -160,7 +160,11 @@ int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtype, void* wo
 /* Optional workspace (device memory of dg_gemm_tn_grouped_workspace_bytes(problems, n) bytes, zero-filled ONCE by the
  * caller and then left to the library between calls on one stream): lets the kernel cut every tile's contraction into
  * two halves run by different workgroups when that shortens the schedule (381 tiles on 256 CUs: 3 rounds of half
- * tiles instead of 2 rounds of whole ones).  The halves are summed first + second, a fixed order.  NULL = no split. */
+ * tiles instead of 2 rounds of whole ones).  The halves are summed first + second, a fixed order.  NULL = no split.
+ * The second half of a tile waits (spins on a flag) for the first half, which an earlier-numbered work item of another
+ * workgroup computes: the launch uses at most one workgroup per CU and every workgroup takes its items in increasing order,
+ * so the wait always resolves as long as workgroups that finish make room for the not-yet-resident ones (normal dispatch;
+ * do not run it under a CU mask smaller than half the device). */
 int64_t dg_gemm_tn_grouped_workspace_bytes(const dg_tn_problem* problems, int n);
 
 /* out[i] = sum_{g < n_partials} partials[g*stride + i], i < n.  Deterministic order. */
