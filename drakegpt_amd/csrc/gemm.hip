@@ -246,13 +246,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
 // 384 = 1.5 rounds for N = 384) and amortises the per-tile epilogue and barrier costs over 1.5x the MFMA work.
 // EPI: which epilogue options exist at compile time.  0 = all of them behind run-time flags (any combination, plus the
 // DG_GEMM_DBG ablations and s_memtime stamps); 1 = plain store; 2 = bias + ReLU + sign-bit emission (Linear+ReLU of
-// FeedForward); 3 = bias + dropout + residual (proj / second FFN Linear); 4 = sign-bit mask (dX of the second FFN Linear).
+// FeedForward); 3 = bias + dropout + residual (proj / second FFN Linear); 4 = sign-bit mask (dX of the second FFN Linear);
+// 5 = bias only (lm_head: 1.65 GB of fp32 logits at the GPT-2 vocabulary).
 // The specialised forms are straight-line code: no uniform branch per option and per K step, so the scheduler can overlap
 // the epilogue's loads, lane exchanges and stores.
 template <typename TO, bool PF, int NJ, int EPI>
 __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     constexpr bool GEN = EPI == 0;
-    const float* const e_bias = (GEN || EPI == 2 || EPI == 3) ? p.bias : nullptr;
+    const float* const e_bias = (GEN || EPI == 2 || EPI == 3 || EPI == 5) ? p.bias : nullptr;
     const int e_relu = GEN ? p.relu : (EPI == 2 ? 1 : 0);
     const void* const e_mask = GEN ? p.relu_mask : nullptr;
     const int e_drop = (GEN || EPI == 3) ? p.drop : 0;
@@ -692,6 +693,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
                 else if (a->out_dtype == DG_BF16 && a->bias && a->relu && a->sign_bits_out && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits) epi = 2;
                 else if (a->out_dtype == DG_F32 && a->bias && p.drop && a->residual && !a->relu && !a->relu_mask && !a->sign_bits && !a->sign_bits_out) epi = 3;
                 else if (a->out_dtype == DG_BF16 && pf && !a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits_out) epi = 4;
+                else if (a->out_dtype == DG_F32 && a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits && !a->sign_bits_out) epi = 5;
             }
         }
 #define DG_WS_LAUNCH(NJ_) do { \
@@ -700,6 +702,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
             else if (epi == 2) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, NJ_, 2>), pgrid, wsb, 0, s, p); \
             else if (epi == 3) hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, NJ_, 3>), pgrid, wsb, 0, s, p); \
             else if (epi == 4) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true, NJ_, 4>), pgrid, wsb, 0, s, p); \
+            else if (epi == 5) hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, NJ_, 5>), pgrid, wsb, 0, s, p); \
             else if (pf && a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true, NJ_, 0>), pgrid, wsb, 0, s, p); \
             else if (pf) hipLaunchKernelGGL((gemm_nt_ws_kernel<float, true, NJ_, 0>), pgrid, wsb, 0, s, p); \
             else if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, NJ_, 0>), pgrid, wsb, 0, s, p); \
@@ -964,11 +967,11 @@ __global__ __launch_bounds__(768) void gemm_tn_ws_kernel(TnParams p) {
 // (of any problem of the group) with ONE continuous stage pipeline and each tile runs over the whole
 // contraction, so there are no split-K slabs to write, re-read and reduce (they were ~790 MB per step)
 // and no per-matrix launch: 651 tiles of 256 K steps instead of 25 launches of <= 256 short workgroups.
-#define TN_MAX_GROUP 32
+#define TN_MAX_GROUP 64                       // 24 + 64 x 56 B of kernel arguments (limit 4 KB): GPT-2-small's 49 matrices in one launch
 struct TnProblem {
     const char* A; const char* B; float* out;
-    int64_t lda_b, ldb_b, ldo;
-    int P, Q, R, tiles_q, tile_begin, pad;
+    int lda_b, ldb_b, ldo;                    // byte strides of A and B (< 2 GB), element stride of out
+    int P, Q, R, tiles_q, tile_begin;
 };
 // ws (256-row-tile kernel only): split-K workspace, [total_tiles][8 waves][16 KB] fp32 partials then [total_tiles][8] flags
 struct TnGroup { int n, total_tiles; int splits, tiles_pad; char* ws; TnProblem pr[TN_MAX_GROUP]; };
@@ -1007,7 +1010,7 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped_kernel(TnGroup gp) {
             locate(ti, pi, p0, q0);
             const TnProblem& pr = gp.pr[pi];
             nk_iss = pr.R / 64;
-            stepA = 64 * pr.lda_b; stepB = 64 * pr.ldb_b;
+            stepA = 64 * (int64_t)pr.lda_b; stepB = 64 * (int64_t)pr.ldb_b;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int q = 4 * lw + i;
@@ -1484,6 +1487,7 @@ extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtyp
         if (!q.A || !q.B || !q.out || q.R <= 0 || q.P <= 0 || q.Q <= 0 || q.R % 64) return DG_ERR_ARG;
         if (q.lda % 8 || q.ldb % 8 || !dg_aligned16(q.A) || !dg_aligned16(q.B)) return DG_ERR_ALIGN;
         if (q.lda < q.P || q.ldb < q.Q || q.ldo < q.Q) return DG_ERR_ARG;
+        if (q.lda >= (1 << 30) || q.ldb >= (1 << 30) || q.ldo >= (1ll << 31)) return DG_ERR_ARG;
         if (((q.P + 7) / 8) * 8 > q.lda || ((q.Q + 7) / 8) * 8 > q.ldb) return DG_ERR_ARG;
     }
     if (workspace && (!dg_aligned16(workspace) || workspace_bytes < dg_gemm_tn_grouped_workspace_bytes(problems, n))) return DG_ERR_ARG;
@@ -1498,11 +1502,10 @@ extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtyp
             const dg_tn_problem& q = problems[base + i];
             TnProblem& t = gp.pr[i];
             t.A = (const char*)q.A; t.B = (const char*)q.B; t.out = q.out;
-            t.lda_b = q.lda * 2; t.ldb_b = q.ldb * 2; t.ldo = q.ldo;
+            t.lda_b = (int)(q.lda * 2); t.ldb_b = (int)(q.ldb * 2); t.ldo = (int)q.ldo;
             t.P = q.P; t.Q = q.Q; t.R = q.R;
             t.tiles_q = (q.Q + 127) / 128;
             t.tile_begin = tiles;
-            t.pad = 0;
             tiles += ((q.P + tile_p - 1) / tile_p) * t.tiles_q;
             const int nk = q.R / 64;
             if (nk < nk_min) nk_min = nk;
