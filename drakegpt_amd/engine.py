@@ -292,7 +292,7 @@ class TrainEngine:
             h, sf = S.ffn_fwd(run, h, P["ln2w"], P["ln2b"], P["w1"], P["b1"], P["w2"], P["b2"], True, p, l)
             if want_grad:
                 saved.append((sa, sf))
-        logits, (xa,) = S.linear_fwd(run, h, self.param_view("lm.w"), self.param_view("lm.b"))
+        logits, (xa,) = S.linear_fwd(run, h, self.param_view("lm.w"), self.param_view("lm.b"), pad_rows=True)
         if y_idx is None:
             return logits, None, None
         dlogits = None
