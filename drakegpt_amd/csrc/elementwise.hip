@@ -567,6 +567,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     const float step_size = lr / bc1;
     const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
     const float decay = 1.f - lr * wd;
+    const bool shadow_vec = (((uintptr_t)shadow) & 7) == 0;
     int64_t gs = (int64_t)gridDim.x * blockDim.x;
     int64_t n4 = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gs) {
@@ -580,9 +581,18 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
             float denom = sqrtf(vj) * inv_sqrt_bc2 + eps;
             pj -= step_size * (mj / denom);
             pp[j] = pj; mm[j] = mj; vv[j] = vj;
-            if (shadow) shadow[i * 4 + j] = (bf16_t)pj;
         }
         ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+        if (shadow) {                                            // one 8-byte store (shadow + 4 i is 8-byte aligned with p)
+            bf16x4 sh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sh[j] = (bf16_t)pp[j];
+            if (shadow_vec) *(bf16x4*)(shadow + i * 4) = sh;
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) shadow[i * 4 + j] = sh[j];
+            }
+        }
     }
     for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gs) {
         float gj = g[i] * grad_scale;
