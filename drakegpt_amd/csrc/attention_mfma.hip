@@ -174,7 +174,7 @@ __device__ __forceinline__ void store_N_acc(char* img, const f32x16 (&acc)[2], f
 template <bool DROP>      // dropout on the probabilities (compile-time: no per-element uniform branch)
 __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block, pointers and loop bounds live in SGPRs
     int64_t bh; int blk; bool valid;
     attn_item(p, wave, bh, blk, valid);
     if (!valid) return;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
 template <bool DROP>      // dropout on the probabilities (compile-time: no per-element uniform branch)
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block, pointers and loop bounds live in SGPRs
     int64_t bh; int blk; bool valid;
     attn_item(p, wave, bh, blk, valid);
     if (!valid) return;
@@ -313,12 +313,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
     tile_load(rk, Kb, ld, 0, T, lane);
     tile_load(rv, Vb, ld, 0, T, lane);
     for (int kt = 0; kt <= qb; ++kt) {
-        tile_store<false>(imgK, rk, lane);
-        tile_store<true>(imgKt, rk, lane);
-        tile_store<false>(imgV, rv, lane);
+        // LDS / global addresses are recomputed from the lane id every iteration (opaque to the optimiser) instead of being
+        // hoisted into ~20 loop-invariant VGPRs: the kernel wants 186-219 VGPRs otherwise, and at three workgroups per CU
+        // (168) the overflow went to scratch (no-dropout variant: 68 spilled registers, 65 -> 55 us for the backward pair).
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        tile_store<false>(imgK, rk, ln);
+        tile_store<true>(imgKt, rk, ln);
+        tile_store<false>(imgV, rv, ln);
         if (kt < qb) {
-            tile_load(rk, Kb, ld, (kt + 1) * TILE, T, lane);
-            tile_load(rv, Vb, ld, (kt + 1) * TILE, T, lane);
+            tile_load(rk, Kb, ld, (kt + 1) * TILE, T, ln);
+            tile_load(rv, Vb, ld, (kt + 1) * TILE, T, ln);
         }
         __builtin_amdgcn_wave_barrier();
         f32x16 S, dP;
@@ -326,8 +331,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
         for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgK, ks, lane), qf[ks], S, 0, 0, 0);
-            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgV, ks, lane), gf[ks], dP, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgK, ks, ln), qf[ks], S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgV, ks, ln), gf[ks], dP, 0, 0, 0);
         }
         const int k0 = kt * TILE;
         const uint32_t wtile = wbase + (uint32_t)k0 * DG_WEYL;
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
             char* tb = p.tiles + attn_tile_index(p, bh, qb, kt);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int cc = lane + 64 * i;
+                const int cc = ln + 64 * i;
                 *(u32x4*)(tb + cc * 16) = *(const u32x4*)(imgV + cc * 16);
             }
         }
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
             const bf16x8 df = pack8(S, s);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-                dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(imgKt, dt, s, lane), df, dQ[dt], 0, 0, 0);
+                dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(imgKt, dt, s, ln), df, dQ[dt], 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
 template <bool DROP>      // dropout on the probabilities (compile-time: no per-element uniform branch)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block, pointers and loop bounds live in SGPRs
     int64_t bh; int blk; bool valid;
     attn_item(p, wave, bh, blk, valid);
     if (!valid) return;
@@ -506,7 +511,7 @@ bool dg_attn_mfma_supported(int B, int T, int NH, int H) {
 #define WAVE_LDS_DKVT 12288
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_tiles_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block, pointers and loop bounds live in SGPRs
     int64_t bh; int blk; bool valid;
     attn_item(p, wave, bh, blk, valid);
     if (!valid) return;
