@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
     __shared__ __attribute__((aligned(16))) char lds_raw[NT_LDS_BYTES];   // operands [buf][A|B][16 KB]; the epilogue staging reuses it
     char (*lds)[2][BM * 128] = reinterpret_cast<char (*)[2][BM * 128]>(lds_raw);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
     const int wm = wave >> 1, wn = wave & 1;
     const int tile = dg_xcd_remap(blockIdx.x, p.n_tiles);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     constexpr int STAGE = 16384 + BNW * 128;                   // A [128][128 B] + B [BNW][128 B]
     constexpr int PPA = WS_PPL, PPB = BNW / 8 / WS_NLOAD;      // 1 KB pieces per loader wave per stage
     __shared__ __attribute__((aligned(16))) char lds[GL_NST * STAGE];          // 128 KB / 160 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
     const int wm = wave >> 1, wn = wave & 1;
     const int G = gridDim.x;
     const int my_tiles = (p.n_tiles - (int)blockIdx.x + G - 1) / G;
@@ -770,7 +770,7 @@ __device__ __forceinline__ u32x4 tn_frag_bf16(const char* tile, int r0, int col0
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnParams p) {
     constexpr int BR = 64;
     __shared__ __attribute__((aligned(16))) char lds[2][2][BR * 256];      // 64 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
     const int wp = wave >> 1, wq = wave & 1;
     int tile, split;
     tn_work(p, tile, split);
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(TnParams p) {
 //      reaches outputs which are not stored.  Accumulators transposed (mfma(B, A)): 16-byte stores.
 __global__ __launch_bounds__(768) void gemm_tn_ws_kernel(TnParams p) {
     __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
     const int wp = wave >> 1, wq = wave & 1;
     int tile, split;
     tn_work(p, tile, split);
@@ -978,7 +978,7 @@ struct TnGroup { int n, total_tiles; int splits, tiles_pad; char* ws; TnProblem 
 
 __global__ __launch_bounds__(768) void gemm_tn_grouped_kernel(TnGroup gp) {
     __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
     const int wp = wave >> 1, wq = wave & 1;
     const int G = gridDim.x;
     const int my_tiles = (gp.total_tiles - (int)blockIdx.x + G - 1) / G;
@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped_kernel(TnGroup gp) {
 #define TN2_NST 3
 __global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
     __shared__ __attribute__((aligned(16))) char lds[TN2_NST * TN2_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
     const int G = gridDim.x;
     // Work items: (tile, K half).  With splits == 2 every tile is cut into two K halves handled by different workgroups one
     // round apart (all first halves come first in the item order): 381 tiles on 256 CUs then cost 3 rounds of 128 K steps
@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
 __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(TnParams p) {
     constexpr int BR = 32;
     __shared__ __attribute__((aligned(16))) float lds[2][2][BR * TNF_PITCH];     // 73.7 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
     const int wp = wave >> 1, wq = wave & 1;
     int tile, split;
     tn_work(p, tile, split);

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                               const float* __restrict__ beta, TO* __restrict__ y,
                               float* __restrict__ mean, float* __restrict__ rstd, int M, int C, float eps) {
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * LN_RPW;
+    const int row0 = (blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * LN_RPW;
     if (row0 >= M) return;
     const float invC = 1.f / (float)C;
     if (VEC) {
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
                               int M, int C, int rows_per) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][NW][C]
     constexpr int NW = NTHREADS / 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int m_begin = blockIdx.x * rows_per;
     int m_end = m_begin + rows_per; if (m_end > M) m_end = M;
     const float invC = 1.f / (float)C;
