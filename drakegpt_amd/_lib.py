@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdrakegpt_hip.so")
 
 DG_F32 = 0
 DG_BF16 = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GemmNtArgs(C.Structure):
@@ -37,6 +37,9 @@ class GemmNtArgs(C.Structure):
         ("sign_bits_out", C.c_void_p),
         ("sign_bits", C.c_void_p),
         ("sign_bits_bytes", C.c_int64),
+        ("colsum_part", C.c_void_p),
+        ("colsum_ld", C.c_int64),
+        ("colsum_rows", C.c_int32),
     ]
 
 
@@ -64,6 +67,8 @@ SIGNATURES = {
     "dg_layernorm_bwd_fused": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _vp, _u32, _vp, _vp],
     "dg_gemm_nt": [C.POINTER(GemmNtArgs), _vp],
     "dg_gemm_nt_sign_bits_supported": [C.POINTER(GemmNtArgs)],
+    "dg_gemm_nt_colsum_supported": [C.POINTER(GemmNtArgs)],
+    "dg_gemm_nt_colsum_rows": [C.POINTER(GemmNtArgs)],
     "dg_gemm_nt_sign_bits_bytes": [_i, _i],
     "dg_gemm_tn": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp],
     "dg_gemm_tn_grouped": [C.POINTER(TnProblem), _i, _i, _vp, _i64, _vp],

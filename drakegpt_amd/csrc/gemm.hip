@@ -66,6 +66,8 @@ struct NtParams {
     int relu;
     const void* relu_mask; int64_t ldmask;
     unsigned char* bits_out; const unsigned char* bits_in;   // one-bit-per-element ReLU mask, lane-ordered (wave-specialised kernel only)
+    float* colsum_part; int64_t colsum_ld;                     // EPI 6: column sums of the output as partial rows (nullable)
+    int cs_accum;                                              // EPI 6: 1 = one partial row per (workgroup, wave row), 0 = per 32 rows
     const float* residual; int64_t ldr;
     float inv_keep; uint32_t thr; int drop;
     const uint32_t* rng_state; uint32_t site;
@@ -74,6 +76,11 @@ struct NtParams {
     unsigned long long* stamps;   // diagnostic build aid: per-workgroup s_memtime stamps (NULL in production)
     int dbg;      // ablation only (DG_GEMM_DBG): 1 = no operand loads after the first stage, 2 = no LDS reads / MFMA, 3 = no stores, 4 = 1 + 3
 };
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
 
 // Row-wise epilogue over a wave's staged fp32 tile (ROWS x 64, pitch EPI_PITCH floats): every lane
 // handles 4 consecutive columns, so the global stores are whole 128/256-byte row segments instead of
@@ -258,7 +265,8 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     const void* const e_mask = GEN ? p.relu_mask : nullptr;
     const int e_drop = (GEN || EPI == 3) ? p.drop : 0;
     const float* const e_res = (GEN || EPI == 3) ? p.residual : nullptr;
-    const unsigned char* const e_bin = (GEN || EPI == 4) ? p.bits_in : nullptr;
+    const unsigned char* const e_bin = (GEN || EPI == 4 || EPI == 6) ? p.bits_in : nullptr;
+    float* const e_cs = (EPI == 6) ? p.colsum_part : nullptr;    // interior tiles only: the host picks EPI 6 only when every tile is one
     unsigned char* const e_bout = (GEN || EPI == 2) ? p.bits_out : nullptr;
     const int e_dbg = GEN ? p.dbg : 0;
     unsigned long long* const e_stamps = GEN ? p.stamps : nullptr;
@@ -375,6 +383,39 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     // Epilogue straight from the accumulators.  acc[i][j] of lane (fr, fg) is row i*16+fr, columns j*16+fg*4..+3;
     // swapping the odd 16-lane rows of acc[i][2q] with the even rows of acc[i][2q+1] leaves each lane with 8
     // consecutive columns starting at (2q + (fg&1))*16 + (fg>>1)*8.
+    // EPI 6: column sums of the output (the bias gradient of the Linear this dX belongs to), fp32, of the values before
+    // rounding to TO.  A lane adds up its own rows; the 16 lanes that share fg hold the 16 row pairs of the same 8 columns,
+    // so a flush is four DPP steps inside the 16-lane row and lanes 0 / 16 / 32 / 48 write one partial row.  When all tiles
+    // of a workgroup lie in one column block (cs_accum, decided on the host) the flush happens once per launch instead of
+    // once per tile: the DPP steps of four tiles cost the dX GEMM of FeedForward 3 us of VALU time with no MFMA beside it.
+    float cs_acc[EPI == 6 ? NJ / 2 : 1][8];
+#pragma unroll
+    for (int q = 0; q < (EPI == 6 ? NJ / 2 : 1); ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs_acc[q][e] = 0.f;
+    auto cs_flush = [&](int part_row, int n0) {
+        if constexpr (EPI == 6) {
+#pragma unroll
+            for (int q = 0; q < NJ / 2; ++q) {
+                float c8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = cs_acc[q][e];
+                    x += dpp_f32<0xB1>(x);      // quad_perm [1,0,3,2]
+                    x += dpp_f32<0x4E>(x);      // quad_perm [2,3,0,1]
+                    x += dpp_f32<0x141>(x);     // row_half_mirror
+                    x += dpp_f32<0x140>(x);     // row_mirror
+                    c8[e] = x;
+                    cs_acc[q][e] = 0.f;
+                }
+                if (fr == 0) {
+                    float* cp = e_cs + (int64_t)part_row * p.colsum_ld + n0 + wn * (NJ * 16) + (fg & 1) * 16 + (fg >> 1) * 8 + 32 * q;
+                    *(f32x4*)cp = (f32x4){c8[0], c8[1], c8[2], c8[3]};
+                    *(f32x4*)(cp + 4) = (f32x4){c8[4], c8[5], c8[6], c8[7]};
+                }
+            }
+        }
+    };
     auto epilogue = [&](int ti) -> bool {
         const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
         const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BNW;
@@ -558,7 +599,14 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
                     *(bf16x8*)cp = o;
                 }
+                if constexpr (EPI == 6) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cs_acc[q][e] += v[e];
+                }
             }
+        }
+        if constexpr (EPI == 6) {
+            if (!p.cs_accum) cs_flush((m0 >> 5) + wm, n0);
         }
     };
     auto finish_tile = [&](int ti) {
@@ -595,6 +643,15 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
         if (e_dbg != 2) mma_all(fa1, fb1);
         stamp();
         if (++kt == nk) { finish_tile(tile_i); kt = 0; ++tile_i; stamp(); }
+    }
+    if constexpr (EPI == 6) {
+        if (p.cs_accum && total > 0) {
+            // rank of this workgroup among those whose tiles lie in the same column block (see dg_gemm_nt_colsum_rows)
+            const int tile0 = dg_xcd_remap((int)blockIdx.x, p.n_tiles);
+            const int per_xcd = (G >> 3) / p.tiles_n;
+            const int rank = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3) / p.tiles_n;
+            cs_flush(4 * rank + wm, (tile0 % p.tiles_n) * BNW);
+        }
     }
 }
 
@@ -634,6 +691,34 @@ extern "C" int64_t dg_gemm_nt_sign_bits_bytes(int M, int N) {
     return (int64_t)((M + BM - 1) / BM) * ((N + bn - 1) / bn) * (BM * bn / 8);
 }
 
+// Column sums in the epilogue: only the sign-bit-masked dX form (the one whose output is the pre-activation gradient a bias
+// gradient is the column sum of), every tile interior and on the vector path, debug switches off.
+extern "C" int dg_gemm_nt_colsum_supported(const dg_gemm_nt_args* a) {
+    if (!a || !dg_gemm_nt_sign_bits_supported(a) || !a->sign_bits || a->out_dtype != DG_BF16) return 0;
+    if (a->bias || a->relu || a->relu_mask || a->residual || a->sign_bits_out || (a->dropout_p > 0.f && a->rng_state)) return 0;
+    static const int pf_mode = [] { const char* e = getenv("DG_GEMM_PF"); return e ? atoi(e) : 1; }();
+    static const int dbg = [] { const char* e = getenv("DG_GEMM_DBG"); return e ? atoi(e) : 0; }();
+    static const int cs_mode = [] { const char* e = getenv("DG_GEMM_COLSUM"); return e ? atoi(e) : 1; }();   // 0 = never (A/B runs)
+    if (!pf_mode || dbg || g_stamp_buffer || !cs_mode) return 0;
+    const int bn = dg_nt_wide(a->N) ? 192 : 128;
+    return a->M % BM == 0 && a->N % bn == 0 && a->ldc % 8 == 0 && dg_aligned16(a->C);
+}
+// Number of partial rows the call writes (0 = not supported).  Tile t of workgroup b is remap(b + t G) = base(b % 8) + b / 8 +
+// t G / 8, so with (G / 8) % tiles_n == 0 all tiles of a workgroup share one column block and it writes ONE partial row per
+// wave row at the end: 4 G / tiles_n rows, indexed 4 rank + wave row with rank = (b % 8) (G / 8 / tiles_n) + (b / 8) / tiles_n,
+// which numbers the workgroups of one column block 0 .. G / tiles_n - 1.  Otherwise one partial row per 32 rows of C.
+static bool dg_nt_cs_accum(int n_tiles, int tiles_n) {
+    const int G = n_tiles < dg_num_cus() ? n_tiles : dg_num_cus();
+    return G % 8 == 0 && (G / 8) % tiles_n == 0;
+}
+extern "C" int dg_gemm_nt_colsum_rows(const dg_gemm_nt_args* a) {
+    if (!dg_gemm_nt_colsum_supported(a)) return 0;
+    const int bn = dg_nt_wide(a->N) ? 192 : 128;
+    const int tiles_n = a->N / bn, n_tiles = (a->M / BM) * tiles_n;
+    const int G = n_tiles < dg_num_cus() ? n_tiles : dg_num_cus();
+    return dg_nt_cs_accum(n_tiles, tiles_n) ? 4 * G / tiles_n : a->M / 32;
+}
+
 extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return DG_ERR_ARG;
     const int esz = a->in_dtype == DG_BF16 ? 2 : 4;
@@ -648,6 +733,9 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
         if (!dg_gemm_nt_sign_bits_supported(a) || a->sign_bits_bytes < dg_gemm_nt_sign_bits_bytes(a->M, a->N) ||
             (a->sign_bits && a->relu_mask)) return DG_ERR_ARG;
     }
+    if (a->colsum_part && (!dg_gemm_nt_colsum_supported(a) || a->colsum_rows < dg_gemm_nt_colsum_rows(a) || a->colsum_ld < a->N ||
+                           a->colsum_ld % 4 || !dg_aligned16(a->colsum_part)))
+        return DG_ERR_ARG;
     NtParams p;
     p.A = (const char*)a->A; p.lda_b = a->lda * esz;
     p.B = (const char*)a->B; p.ldb_b = a->ldb * esz;
@@ -656,6 +744,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
     p.bias = a->bias; p.relu = a->relu;
     p.relu_mask = a->relu_mask; p.ldmask = a->ldmask;
     p.bits_out = a->sign_bits_out; p.bits_in = a->sign_bits;
+    p.colsum_part = a->colsum_part; p.colsum_ld = a->colsum_ld; p.cs_accum = 0;
     p.residual = a->residual; p.ldr = a->ldr;
     p.drop = (a->dropout_p > 0.f && a->rng_state) ? 1 : 0;
     p.inv_keep = 1.f / (1.f - a->dropout_p);
@@ -683,6 +772,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
             p.n_tiles = tiles_m * p.tiles_n;
             pgrid = dim3(p.n_tiles < dg_num_cus() ? p.n_tiles : dg_num_cus());
         }
+        p.cs_accum = dg_nt_cs_accum(p.n_tiles, p.tiles_n) ? 1 : 0;
         const dim3 wsb(512 + 64 * WS_NLOAD);
         // epilogue specialisation (see the kernel's EPI parameter); anything else, and every debug run, takes the generic form
         int epi = 0;
@@ -692,7 +782,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
                 if (plain) epi = 1;
                 else if (a->out_dtype == DG_BF16 && a->bias && a->relu && a->sign_bits_out && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits) epi = 2;
                 else if (a->out_dtype == DG_F32 && a->bias && p.drop && a->residual && !a->relu && !a->relu_mask && !a->sign_bits && !a->sign_bits_out) epi = 3;
-                else if (a->out_dtype == DG_BF16 && pf && !a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits_out) epi = 4;
+                else if (a->out_dtype == DG_BF16 && pf && !a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits_out) epi = a->colsum_part ? 6 : 4;
                 else if (a->out_dtype == DG_F32 && a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits && !a->sign_bits_out) epi = 5;
             }
         }
@@ -703,6 +793,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
             else if (epi == 3) hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, NJ_, 3>), pgrid, wsb, 0, s, p); \
             else if (epi == 4) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true, NJ_, 4>), pgrid, wsb, 0, s, p); \
             else if (epi == 5) hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, NJ_, 5>), pgrid, wsb, 0, s, p); \
+            else if (epi == 6) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true, NJ_, 6>), pgrid, wsb, 0, s, p); \
             else if (pf && a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true, NJ_, 0>), pgrid, wsb, 0, s, p); \
             else if (pf) hipLaunchKernelGGL((gemm_nt_ws_kernel<float, true, NJ_, 0>), pgrid, wsb, 0, s, p); \
             else if (a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, NJ_, 0>), pgrid, wsb, 0, s, p); \

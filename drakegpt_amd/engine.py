@@ -99,6 +99,14 @@ class FlatSink:
         assert shape == (N,), (key, shape, N)
         return self.e.vparts[0, off:off + N], self.e.layB.size, self.e.G
 
+    def vector_rows(self, key, N, rows):
+        off, shape = self.e.layB.entries[key]
+        assert shape == (N,), (key, shape, N)
+        if rows > self.e.vparts.shape[0]:
+            return None
+        # partial rows beyond `rows` are never written for this key: they stay zero from allocation
+        return self.e.vparts[:rows, off:off + N]
+
     def direct(self, key, shape=None):
         return self.e.grad_view(key)
 
@@ -208,7 +216,10 @@ class TrainEngine:
         if self.grouped_dw and ops.layernorm_bwd_fused_supported(self.C) and (self.C // 4) * 8 >= S.pad_to(self.V, 8):
             self.onehot = torch.zeros((self.M, S.pad_to(self.V, 8)), dtype=torch.bfloat16, device=dev)
         self.slabs = None if self.grouped_dw else torch.zeros((self.S, self.layA.size), dtype=torch.float32, device=dev)
-        self.vparts = torch.zeros((self.G, self.layB.size), dtype=torch.float32, device=dev)
+        # partial rows of the bias / LayerNorm gradients: G row chunks, or as many as the GEMM epilogue that emits the column
+        # sums (FeedForward's first bias) asks for; rows a producer never writes stay zero
+        self.Gv = max(self.G, ops.gemm_nt_colsum_rows(self.act, self.M, 4 * self.C, self.C))
+        self.vparts = torch.zeros((self.Gv, self.layB.size), dtype=torch.float32, device=dev)
         NH, H = self.NH, self.H
 
         def adopt(param: torch.nn.Parameter, view: Tensor):
@@ -337,7 +348,7 @@ class TrainEngine:
             sink.flush()
         else:
             ops.reduce_partials(self.slabs, self.layA.size, self.S, self.gflat[self.offA:], self.layA.size)
-        ops.reduce_partials(self.vparts, self.layB.size, self.G, self.gflat[self.offB:], self.layB.size)
+        ops.reduce_partials(self.vparts, self.layB.size, self.Gv, self.gflat[self.offB:], self.layB.size)
 
     def _prog_fwd_bwd(self):
         """gather the batch, forward, backward, reduce the gradient partials"""

@@ -167,9 +167,10 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
             bias: Optional[Tensor] = None, relu: bool = False, relu_mask: Optional[Tensor] = None,
             residual: Optional[Tensor] = None, dropout_p: float = 0.0, rng_state: Optional[Tensor] = None,
             site: int = 0, out: Optional[Tensor] = None, sign_bits_out: Optional[Tensor] = None,
-            sign_bits: Optional[Tensor] = None) -> Tensor:
+            sign_bits: Optional[Tensor] = None, colsum_part: Optional[Tensor] = None) -> Tensor:
     """out[M,N] = epilogue(A[M,K] @ Bm[N,K]^T).  A/Bm may carry padding columns beyond K (ld > K).
-    sign_bits_out / sign_bits: opaque uint8 buffer (new_sign_bits) holding one bit per element, out > 0."""
+    sign_bits_out / sign_bits: opaque uint8 buffer (new_sign_bits) holding one bit per element, out > 0.
+    colsum_part: fp32 [gemm_nt_colsum_rows(...), N] (rows may be strided): partial rows of the column sums of out."""
     _chk(A, "A", contiguous=False)
     _chk(Bm, "B", contiguous=False)
     if A.dtype != Bm.dtype:
@@ -205,6 +206,11 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
             _chk(t, name, torch.uint8)
             setattr(a, name, _p(t))
             a.sign_bits_bytes = t.numel()
+    if colsum_part is not None:
+        _chk(colsum_part, "colsum_part", torch.float32, contiguous=False)
+        if colsum_part.shape[1] < N:
+            raise RuntimeError("gemm_nt: colsum_part must have N columns")
+        a.colsum_part, a.colsum_ld, a.colsum_rows = _p(colsum_part), _ld(colsum_part), colsum_part.shape[0]
     check(lib.dg_gemm_nt(C.byref(a), _stream()), "dg_gemm_nt")
     return out
 
@@ -215,6 +221,16 @@ def gemm_nt_sign_bits_supported(dtype: torch.dtype, N: int, K: int) -> bool:
     a.M, a.N, a.K = 128, N, K
     a.in_dtype = a.out_dtype = dt_code(dtype)
     return bool(lib.dg_gemm_nt_sign_bits_supported(C.byref(a)))
+
+
+def gemm_nt_colsum_rows(dtype: torch.dtype, M: int, N: int, K: int) -> int:
+    """partial rows the sign_bits-consuming dg_gemm_nt of this shape writes into colsum_part (0: column sums not offered)"""
+    a = GemmNtArgs()
+    a.M, a.N, a.K = M, N, K
+    a.in_dtype = a.out_dtype = dt_code(dtype)
+    a.ldc = N
+    a.sign_bits = 16        # any non-null, aligned pointer value: the query only looks at which operands are present
+    return int(lib.dg_gemm_nt_colsum_rows(C.byref(a)))
 
 
 def new_sign_bits(M: int, N: int, device) -> Tensor:

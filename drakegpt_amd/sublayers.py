@@ -116,6 +116,12 @@ class LocalSink:
         self._pending[key] = (part, N, self.G, (N,))
         return part, N, self.G
 
+    def vector_rows(self, key: str, N: int, rows: int) -> Tensor:
+        """[rows, N] partial rows for a producer with its own partial count (GEMM epilogue column sums)"""
+        part = torch.empty((rows, N), dtype=torch.float32, device=self.device)
+        self._pending[key] = (part, N, rows, (N,))
+        return part
+
     def direct(self, key: str, shape) -> Tensor:
         t = torch.zeros(shape, dtype=torch.float32, device=self.device)
         self._direct[key] = t
@@ -263,12 +269,22 @@ def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2:
             g = ops.dropout_bwd_cast(dy, run.act, run.p(p), run.rng, site_ffn(layer), colsum_part=part, part_stride=stride,
                                      n_partials=n)
         weight_grad(sink, keys["w2"], g, f, w2.shape[0], w2.shape[1])
-        if bits is not None:
-            df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], sign_bits=bits)
+        cs_part = None
+        vector_rows = getattr(sink, "vector_rows", None)
+        if bits is not None and vector_rows is not None:
+            rows = ops.gemm_nt_colsum_rows(run.act, g.shape[0], w1.shape[0], w2.shape[0])
+            if rows:
+                cs_part = vector_rows(keys["b1"], w1.shape[0], rows)
+        if cs_part is not None:
+            # the b1 gradient (column sums of df) leaves the dX GEMM's epilogue as partial rows
+            df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], sign_bits=bits, colsum_part=cs_part)
         else:
-            df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], relu_mask=f)
-        part, stride, n = sink.vector(keys["b1"], w1.shape[0])
-        ops.colsum(df, part, stride, n)
+            if bits is not None:
+                df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], sign_bits=bits)
+            else:
+                df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], relu_mask=f)
+            part, stride, n = sink.vector(keys["b1"], w1.shape[0])
+            ops.colsum(df, part, stride, n)
     weight_grad(sink, keys["w1"], df, h, w1.shape[0], w1.shape[1])
     if not need_dx:
         return None

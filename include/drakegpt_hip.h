@@ -42,7 +42,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 2   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 3   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -130,9 +130,21 @@ typedef struct dg_gemm_nt_args {
     uint8_t* sign_bits_out;        /* nullable */
     const uint8_t* sign_bits;      /* nullable; excludes relu_mask */
     int64_t sign_bits_bytes;       /* size of either buffer, >= dg_gemm_nt_sign_bits_bytes(M, N) */
+    float* colsum_part;            /* nullable: [colsum_rows][colsum_ld] fp32, see below */
+    int64_t colsum_ld;
+    int32_t colsum_rows;           /* rows of colsum_part, >= dg_gemm_nt_colsum_rows(args) */
 } dg_gemm_nt_args;
 int dg_gemm_nt(const dg_gemm_nt_args* args, void* stream);
 int dg_gemm_nt_sign_bits_supported(const dg_gemm_nt_args* args);
+/* colsum_part: the epilogue also leaves the column sums of C (fp32, of the values before rounding to out_dtype) as
+ * dg_gemm_nt_colsum_rows(args) partial rows: sum them with dg_reduce_partials.  Which rows of C a partial row covers is
+ * the kernel's business (one per 32 rows of C, or one per workgroup and wave row when a workgroup's tiles share their
+ * columns); every partial row is written by every call.  With C = d(pre-activation) of FeedForward's first Linear this is
+ * that Linear's bias gradient (ref: autograd of src/model_component.py:321), for which the step used to re-read all of C
+ * (dg_colsum).  Only for the sign_bits-consuming form with whole tiles: dg_gemm_nt_colsum_supported(args) non-zero,
+ * DG_ERR_ARG otherwise. */
+int dg_gemm_nt_colsum_supported(const dg_gemm_nt_args* args);
+int dg_gemm_nt_colsum_rows(const dg_gemm_nt_args* args);
 int64_t dg_gemm_nt_sign_bits_bytes(int M, int N);
 
 /* GEMM "TN": weight gradients, dW[P,Q] = sum_r A[r,P] * B[r,Q]  (A = dY [R,P], B = X [R,Q]).

@@ -94,6 +94,41 @@ def test_gemm_nt_epilogue(dev, dtype, M, N, K):
     assert abs(frac - (1 - p)) < 0.01, frac
 
 
+@pytest.mark.parametrize("M,N,K,ld", [(256, 1536, 384, 1536), (16384, 1536, 128, 1536), (1024, 384, 128, 400), (4096, 128, 128, 128), (41088, 192, 128, 192)])
+def test_gemm_nt_colsum_epilogue(dev, M, N, K, ld):
+    """the sign-bit-masked dX GEMM also writes partial rows of the column sums of its output (FeedForward's first bias
+    gradient): wide and square tiles, a strided partial buffer, one partial row per 32 rows (16 tiles on 16 workgroups) and
+    one per workgroup and wave row (1024 / 321 tiles, several per workgroup)"""
+    ops = _ops()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(M, K, generator=g).to(bf)
+    B = torch.randn(N, K, generator=g).to(bf)
+    W = torch.randn(N, K, generator=g).to(bf)
+    rows = ops.gemm_nt_colsum_rows(bf, M, N, K)
+    assert 0 < rows <= M // 32
+    bits = ops.new_sign_bits(M, N, dev)
+    f = ops.gemm_nt(A.to(dev), W.to(dev), bf, bias=torch.zeros(N, device=dev), relu=True, sign_bits_out=bits)
+    pos = (f.float().cpu() > 0).double()
+    part = torch.full((rows + 3, ld), 7.0, device=dev)
+    out = ops.gemm_nt(A.to(dev), B.to(dev), bf, sign_bits=bits, colsum_part=part[:rows, :N])
+    ref = (A.double() @ B.double().T) * pos
+    assert rel(out, ref) < 6e-3
+    got = part.cpu().double()
+    assert torch.all(got[rows:] == 7.0) and torch.all(got[:, N:] == 7.0)          # nothing outside [rows, N] is touched
+    assert not torch.any(got[:rows, :N] == 7.0)                                   # every partial row is written
+    assert rel(got[:rows, :N].sum(0), ref.sum(0)) < 1e-5
+    total = torch.empty(N, device=dev)
+    ops.reduce_partials(part, ld, rows, total, N)
+    assert rel(total, ref.sum(0)) < 1e-5
+    # not offered where a tile would be partial, or for fp32 operands; too few partial rows are refused
+    assert ops.gemm_nt_colsum_rows(bf, M + 32, N, K) == 0
+    assert ops.gemm_nt_colsum_rows(bf, M, N + 8, K) == 0
+    assert ops.gemm_nt_colsum_rows(torch.float32, M, N, K) == 0
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(A.to(dev), B.to(dev), bf, sign_bits=bits, colsum_part=part[:rows - 1, :N])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("R,P,Q,S", [(256, 96, 32, 1), (4096, 384, 384, 2), (1000, 80, 384, 3), (640, 1152, 384, 1), (16384, 128, 128, 8), (130, 200, 72, 2)])
 def test_gemm_tn(dev, dtype, R, P, Q, S):
