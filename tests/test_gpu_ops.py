@@ -441,6 +441,19 @@ def test_transpose_cast_batched(dev):
             R = W.shape[0]
             assert torch.equal(Wt[:, :R].cpu(), W.T.to(dt).cpu())
             assert torch.all(Wt[:, R:] == 0)
+    # bf16 -> bf16 (the engine's W^T refresh from the bf16 shadow): 16-byte pieces, ragged edges, an unaligned descriptor
+    bf = torch.bfloat16
+    pairs = []
+    for R, C in shapes + [(200, 72), (64, 64)]:
+        W = torch.randn(R, C, generator=g).to(bf).to(dev)
+        Wt = torch.full((C, (R + 7) // 8 * 8), float("nan"), dtype=bf, device=dev)
+        pairs.append((W, Wt))
+    table = ops.make_transpose_table(pairs, dev)
+    ops.transpose_cast_batched(*table, bf, in_dtype=bf)
+    for W, Wt in pairs:
+        R = W.shape[0]
+        assert torch.equal(Wt[:, :R].cpu(), W.T.cpu())
+        assert torch.all(Wt[:, R:] == 0)
 
 
 def test_argument_validation_rejects_before_launch(dev):
