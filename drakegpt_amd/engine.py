@@ -155,6 +155,7 @@ class TrainEngine:
         self.loss = torch.zeros((), dtype=torch.float32, device=self.dev)
         self.corpus: Optional[Tensor] = None
         self._graphs = None
+        self._eval_graph = None
         self.refresh_shadows()
 
     # -------------------------------------------------------------------------------- layout
@@ -440,6 +441,46 @@ class TrainEngine:
         run = S.Run(act=self.act, rng=None, weights=self.weights)
         _, rows, _ = self._forward(run, x, y, False)
         return ops.reduce_sum(rows, 1.0 / rows.numel())
+
+    @torch.no_grad()
+    def eval_losses(self, data: Tensor, offsets: Tensor) -> Tensor:
+        """losses of offsets.shape[0] forward-only batches (dropout off) drawn from the resident token stream `data` at the
+        window offsets `offsets` [n, B] (int64, on the device): the inner loop of evaluate_loss (ref: src/train.py:66-72)
+        as one gather launch + one captured forward graph per batch and no host synchronisation; returns [n] on the device.
+        Eagerly it was ~55 ctypes launches and a `.item()` per batch -- more host time than the 0.85 ms the GPU needs."""
+        n, B = offsets.shape
+        if B != self.B:
+            raise ValueError(f"eval_losses: batches of {B} rows, the engine was built for {self.B}")
+        out = torch.empty(n, dtype=torch.float32, device=self.dev)
+        if not self.use_graph:
+            for i in range(n):
+                x, y = ops.batch_gather(data, offsets[i], self.T)
+                out[i:i + 1].copy_(self.eval_loss(x, y).view(1))
+            return out
+        if self._eval_graph is None:
+            self.ev_x = torch.zeros((self.B, self.T), dtype=torch.int64, device=self.dev)
+            self.ev_y = torch.zeros((self.B, self.T), dtype=torch.int64, device=self.dev)
+            self.ev_loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+
+            def prog():
+                run = S.Run(act=self.act, rng=None, weights=self.weights)
+                _, rows, _ = self._forward(run, self.ev_x, self.ev_y, False)
+                ops.reduce_sum(rows, 1.0 / rows.numel(), out=self.ev_loss)
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):       # warm-up outside capture
+                prog()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                prog()
+            self._eval_graph = g
+        for i in range(n):
+            ops.batch_gather(data, offsets[i], self.T, self.ev_x, self.ev_y)
+            self._eval_graph.replay()
+            out[i:i + 1].copy_(self.ev_loss)
+        return out
 
     def step_count(self) -> int:
         return int(self.state[2].item())

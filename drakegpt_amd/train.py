@@ -74,6 +74,11 @@ def evaluate_loss(train_data, val_data, model, eval_iters, context_length, batch
     from . import ops
     out = {}
     for name, data in (("train", train_data), ("val", val_data)):
+        if engine is not None and data.is_cuda:
+            # same draws in the same order as the loop below, staged once; the engine replays a captured forward per batch
+            offs = torch.stack([draw_offsets(len(data), context_length, batch_size, generator) for _ in range(eval_iters)])
+            out[name] = engine.eval_losses(data, offs.to(device)).mean().cpu()
+            continue
         losses = torch.zeros(eval_iters)
         for it in range(eval_iters):
             ix = draw_offsets(len(data), context_length, batch_size, generator).to(device)

@@ -154,3 +154,43 @@ def test_train_harness_smoke(dev, tmp_path, capsys):
     assert "blocks.2.sa_head.heads.3.tril" in sd and sd["ln_f.weight"].eq(1).all()
     train.main(["--model", "BlocksLM", "--iters", "4", "--eval-interval", "2", "--eval-iters", "2", "--precision", "fp32", "--no-save",
                 "--sample", "3"])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_captured_evaluation_equals_eager(dev, golden_dir, precision):
+    """evaluate_loss through the engine (one gather + one captured forward per batch, losses kept on the device) gives the
+    same batch losses as the eager eval path, before and after a training step (the graph reads the live weights), and
+    evaluate_loss consumes the CPU generator exactly as the reference's loop does."""
+    from drakegpt_amd import ops, train
+    m, eng, fix = _mk(dev, golden_dir, precision=precision, dropout=0.1)
+    g = torch.Generator().manual_seed(11)
+    data = torch.randint(0, V, (5000,), generator=g).to(dev)
+    offs = torch.randint(5000 - 8, (6, 32), generator=g).to(dev)
+
+    def eager():
+        out = []
+        for i in range(offs.shape[0]):
+            x, y = ops.batch_gather(data, offs[i], 8)
+            out.append(eng.eval_loss(x, y).item())
+        return torch.tensor(out)
+    assert torch.equal(eng.eval_losses(data, offs).cpu(), eager())
+    eng.set_batch(fix["x"][0].to(dev), fix["y"][0].to(dev))
+    eng.step()
+    after = eng.eval_losses(data, offs).cpu()
+    assert torch.equal(after, eager())
+    assert not torch.equal(after[:1], torch.tensor([0.0]))
+    # evaluate_loss: train then val, eval_iters draws of B offsets each from the given generator
+    m.eval()
+    ga, gb = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    got = train.evaluate_loss(data, data[:3000], m, 4, 8, 32, dev, engine=eng, generator=ga)
+    want = {}
+    for name, d in (("train", data), ("val", data[:3000])):
+        ls = []
+        for _ in range(4):
+            ix = torch.randint(len(d) - 8, (32,), generator=gb).to(dev)
+            x, y = ops.batch_gather(d, ix, 8)
+            ls.append(eng.eval_loss(x, y).item())
+        want[name] = sum(ls) / 4
+    for k in want:
+        assert abs(got[k].item() - want[k]) < 1e-6, (k, got, want)
+    assert torch.equal(torch.randint(10, (3,), generator=ga), torch.randint(10, (3,), generator=gb))
