@@ -1225,13 +1225,34 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
     // round apart (all first halves come first in the item order): 381 tiles on 256 CUs then cost 3 rounds of 128 K steps
     // instead of 2 rounds of 256.  The first half publishes its accumulators (per wave: 16 KB + a flag, agent-scope
     // release); the second half adds them after its own K range -- first + second, a fixed order -- and stores.
-    const int n_items = gp.splits * gp.tiles_pad;
-    const int my_items = (n_items - (int)blockIdx.x + G - 1) / G;
-    struct Item { int pi, p0, q0, ka, kb, tile, half; };
+    // splits == 3 ("split the leftover only"): with T = q G + r tiles, every workgroup runs q whole tiles and only the r
+    // leftover tiles are cut in two.  The role goes by XCD (b & 7): even XCDs run the first half of a leftover tile FIRST and
+    // then their whole tiles, odd XCDs their whole tiles and the second half LAST -- the partial is published a whole tile
+    // before it is needed, and all workgroups of one XCD stay at the same K offset of neighbouring tiles (role by workgroup
+    // parity put neighbours 128 K steps apart: no operand sharing in L2, +15 us).  XCD pair (2m, 2m+1), workgroup j = b >> 3
+    // of it: leftover tile 8 (j >> 1) + 2m + (j & 1), i.e. 16 consecutive tiles of each of the two tile ranges.  For the
+    // scaled model (384 tiles, 256 CUs) that is the same 384 K steps per workgroup as cutting every tile, with a third of
+    // the partial traffic (128 instead of 384 tiles x 128 KB written and read back) and a third of the hand-overs.
+    const int q_whole = gp.total_tiles / G;
+    const int lo_x = (int)blockIdx.x & 7, lo_j = (int)blockIdx.x >> 3;
+    const int lo_tile = (gp.splits == 3) ? q_whole * G + 8 * (lo_j >> 1) + 2 * (lo_x >> 1) + (lo_j & 1) : 0;
+    const bool lo_have = gp.splits == 3 && lo_tile < gp.total_tiles;
+    const int lo_half = lo_x & 1;
+    const int n_items = gp.splits == 3 ? 0 : gp.splits * gp.tiles_pad;
+    const int my_items = gp.splits == 3 ? q_whole + (lo_have ? 1 : 0) : (n_items - (int)blockIdx.x + G - 1) / G;
+    struct Item { int pi, p0, q0, ka, kb, tile, half; };         // half: 0 first (publishes), 1 second (adds, stores), 2 whole tile
     auto item = [&](int ii, Item& x) -> bool {                   // false: padding item (nothing to do)
-        const int it = (int)blockIdx.x + ii * G;
-        x.half = it / gp.tiles_pad;
-        const int tl = it - x.half * gp.tiles_pad;
+        int tl;
+        if (gp.splits == 3) {
+            const bool is_half = lo_have && (lo_half == 0 ? ii == 0 : ii == q_whole);
+            if (is_half) { x.half = lo_half; tl = lo_tile; }
+            else { x.half = 2; tl = (int)blockIdx.x + (ii - ((lo_have && lo_half == 0) ? 1 : 0)) * G; }
+        } else {
+            const int it = (int)blockIdx.x + ii * G;
+            x.half = it / gp.tiles_pad;
+            tl = it - x.half * gp.tiles_pad;
+            if (gp.splits == 1) x.half = 2;
+        }
         if (tl >= gp.total_tiles) return false;
         x.tile = dg_xcd_remap(tl, gp.total_tiles);
         int pi = 0;
@@ -1240,8 +1261,8 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
         const int local = x.tile - gp.pr[pi].tile_begin;
         x.pi = pi;
         x.p0 = (local / gp.pr[pi].tiles_q) * 256; x.q0 = (local % gp.pr[pi].tiles_q) * 128;
-        const int nk = gp.pr[pi].R / 64, mid = gp.splits == 2 ? nk / 2 : nk;
-        x.ka = x.half ? mid : 0; x.kb = x.half ? nk : mid;
+        const int nk = gp.pr[pi].R / 64, mid = nk / 2;
+        x.ka = x.half == 1 ? mid : 0; x.kb = x.half == 0 ? mid : nk;
         return true;
     };
     int total = 0;
@@ -1334,7 +1355,7 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
     next_item();
     auto store_tile = [&]() {
         const TnProblem& pr = gp.pr[cx.pi];
-        if (gp.splits == 2) {
+        if (cx.half != 2) {
             float* part = (float*)(gp.ws + ((size_t)cx.tile * 8 + wave) * 16384);
             unsigned* flag = (unsigned*)(gp.ws + (size_t)gp.total_tiles * 8 * 16384) + cx.tile * 8 + wave;
             // The 16 KB of a wave move as 16 x (64 lanes x 16 B) with the sc0 sc1 cache bits: system-scope write-through
@@ -1612,8 +1633,15 @@ extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtyp
             const int64_t whole = (int64_t)((tiles + ncu - 1) / ncu) * nk_max;
             const int64_t halves = (int64_t)((2 * gp.tiles_pad + ncu - 1) / ncu) * ((nk_max + 1) / 2);
             if (halves < whole) { gp.splits = 2; gp.ws = (char*)workspace; }
+            // cut only the leftover tiles when their halves fit into one half round (see the kernel)
+            static const int lo_mode = [] { const char* e = getenv("DG_TN_LEFTOVER"); return e ? atoi(e) : 1; }();   // 0 = cut every tile (A/B runs)
+            const int r = tiles % ncu;
+            if (lo_mode && tiles > ncu && ncu % 16 == 0 && r > 0 && 16 * ((r + 7) / 8) <= ncu) {
+                const int64_t lo = (int64_t)(tiles / ncu) * nk_max + (nk_max + 1) / 2;
+                if (lo <= (gp.splits == 2 ? halves : whole)) { gp.splits = 3; gp.ws = (char*)workspace; }
+            }
         }
-        const int items = gp.splits * gp.tiles_pad;
+        const int items = gp.splits == 3 ? tiles : gp.splits * gp.tiles_pad;
         const int grid = items < ncu ? items : ncu;
         if (tile_p == 256) hipLaunchKernelGGL(gemm_tn_grouped256_kernel, dim3(grid), dim3(768), 0, s, gp);
         else hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(tiles < ncu ? tiles : ncu), dim3(768), 0, s, gp);
