@@ -186,6 +186,39 @@ def test_gemm_tn_grouped(dev, with_short):
                               torch.zeros(64 * 64, device=dev), 64, 64)])
 
 
+@pytest.mark.parametrize("R", [192, 1024])
+def test_gemm_tn_grouped_leftover_split(dev, R):
+    """the training step's own problem set (6 layers x 4 Linears + lm_head + token table = 384 tiles of 256 x 128): with the
+    workspace one whole tile per workgroup plus one half of a leftover tile (R = 192: an odd number of K steps, halves of 1
+    and 2); same results as without the workspace, bit-identical from run to run, flags reset for the next launch"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R)
+    C, V = 384, 80
+    shapes = [(V, C)] + [(C, 4 * C), (4 * C, C), (C, C), (3 * C, C)] * 6 + [(V, C)]
+    assert sum(((P + 255) // 256) * ((Q + 127) // 128) for P, Q in shapes) == 384
+    probs, outs = [], []
+    for P, Q in shapes:
+        A = torch.randn(R, (P + 7) // 8 * 8, generator=g).to(torch.bfloat16).to(dev)
+        B = torch.randn(R, Q, generator=g).to(torch.bfloat16).to(dev)
+        out = torch.full((P * Q,), float("nan"), device=dev)
+        outs.append(out)
+        probs.append((A[:, :P], B, out, P, Q))
+    ws = ops.gemm_tn_grouped_workspace(probs, dev)
+    ops.gemm_tn_grouped(probs, None)
+    whole = [o.clone() for o in outs]
+    for (A, B, _, P, Q), o in zip(probs, whole):
+        assert rel(o.view(P, Q), A.double().T @ B.double()) < 3e-6
+    runs = []
+    for _ in range(2):
+        for o in outs:
+            o.fill_(float("nan"))
+        ops.gemm_tn_grouped(probs, ws)
+        runs.append([o.clone() for o in outs])
+    for a, b, w, (P, Q) in zip(runs[0], runs[1], whole, shapes):
+        assert torch.equal(a, b)
+        assert rel(a, w) < 1e-6, (P, Q)
+
+
 @pytest.mark.parametrize("G,n,stride", [(256, 23104, 23104), (256, 1000, 1024), (37, 4096, 4100), (32, 2050, 2052), (8, 77, 80), (300, 64, 64)])
 def test_reduce_partials(dev, G, n, stride):
     """both kernels (one output per thread / the tall many-partials form), padded strides, run-to-run identical"""
