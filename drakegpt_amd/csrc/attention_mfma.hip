@@ -139,15 +139,15 @@ __device__ __forceinline__ void store_T_acc(char* img, const f32x16 (&acc)[2], f
             bf16x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = (bf16_t)(acc[dt][4 * g + j] * mul_lane);
-            const int d = 32 * dt + 8 * g + 4 * hh;            // 4 consecutive d
-            *(bf16x4*)(img + c * 128 + d * 2) = v;
+            // 4 consecutive d = 32 dt + 8 g + 4 hh: 16-byte chunk 4 dt + g, XOR-ed with the row (= lane) against bank conflicts
+            *(bf16x4*)(img + c * 128 + (((4 * dt + g) ^ (c & 7)) << 4) + 8 * hh) = v;
         }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int cc = lane + 64 * i, row = cc >> 3, ch = cc & 7;
         const int gr = row0 + row;
-        u32x4 v = *(const u32x4*)(img + row * 128 + ch * 16);
+        u32x4 v = *(const u32x4*)(img + row * 128 + ((ch ^ (row & 7)) << 4));
         if (gr < T) *(u32x4*)(base + (int64_t)gr * ld + ch * 8) = v;
     }
 }
@@ -363,8 +363,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
                     pv = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
                     dv = pv;
                 }
-                *(bf16x4*)(imgV + c * 128 + (8 * g + 4 * hh) * 2) = pv;
-                *(bf16x4*)(imgV + c * 128 + 64 + (8 * g + 4 * hh) * 2) = dv;
+                // row = lane: the 16-byte chunk index is XOR-ed with the row so that the 32 lanes of a row-per-lane write do
+                // not all land on the same two banks (unswizzled this was 3.5 conflict cycles per LDS cycle in the PMC pass)
+                *(bf16x4*)(imgV + c * 128 + ((g ^ (c & 7)) << 4) + 8 * hh) = pv;
+                *(bf16x4*)(imgV + c * 128 + (((4 + g) ^ (c & 7)) << 4) + 8 * hh) = dv;
             }
         }
         if (emit) {
@@ -372,8 +374,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
             char* tb = p.tiles + attn_tile_index(p, bh, qb, kt);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int cc = ln + 64 * i;
-                *(u32x4*)(tb + cc * 16) = *(const u32x4*)(imgV + cc * 16);
+                const int cc = ln + 64 * i, row = cc >> 3, ch = cc & 7;
+                *(u32x4*)(tb + cc * 16) = *(const u32x4*)(imgV + row * 128 + ((ch ^ (row & 7)) << 4));
             }
         }
 #pragma unroll
