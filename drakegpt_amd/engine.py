@@ -156,6 +156,7 @@ class TrainEngine:
         self.corpus: Optional[Tensor] = None
         self._graphs = None
         self._eval_graph = None
+        self.force_dp_path = False      # rehearsal hook (tools/dp_rccl_smoke.py): take the multi-rank path with one rank
         self.refresh_shadows()
 
     # -------------------------------------------------------------------------------- layout
@@ -366,8 +367,11 @@ class TrainEngine:
         self._refresh_transposes()
         ops.state_advance(self.state)
 
+    def _dp(self) -> bool:
+        return self.world > 1 or self.force_dp_path
+
     def _allreduce(self):
-        if self.world > 1:
+        if self._dp():
             import torch.distributed as dist
             dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)     # mean = sum * 1/world in AdamW
 
@@ -384,7 +388,7 @@ class TrainEngine:
         self.flat.copy_(snap[0]); self.m_.copy_(snap[1]); self.v_.copy_(snap[2]); self.state.copy_(snap[3])
         self.refresh_shadows()
         torch.cuda.synchronize(self.dev)
-        if self.world == 1:
+        if not self._dp():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._prog_fwd_bwd()
@@ -427,7 +431,7 @@ class TrainEngine:
             return self.loss
         if self._graphs is None:
             self._capture()
-        if self.world == 1:
+        if not self._dp():
             self._graphs[0].replay()
         else:
             self._graphs[0].replay()

@@ -194,3 +194,17 @@ def test_captured_evaluation_equals_eager(dev, golden_dir, precision):
     for k in want:
         assert abs(got[k].item() - want[k]) < 1e-6, (k, got, want)
     assert torch.equal(torch.randint(10, (3,), generator=ga), torch.randint(10, (3,), generator=gb))
+
+
+def test_rccl_data_parallel_path_world_size_one():
+    """the multi-rank step (backward graph -> RCCL all-reduce of the flat gradient -> optimizer graph) on a world-size-1
+    "nccl" group in a child process: same losses as the single-graph step (tools/dp_rccl_smoke.py)."""
+    import random
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(random.randint(20000, 40000)), RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_rccl_smoke.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "RCCL data-parallel path ok" in r.stdout
