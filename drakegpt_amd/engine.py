@@ -156,6 +156,8 @@ class TrainEngine:
         self.corpus: Optional[Tensor] = None
         self._graphs = None
         self._eval_graph = None
+        import os
+        self.last_block_act = os.environ.get("DG_LAST_BLOCK_ACT", "1") != "0"      # 0: fp32 output + cast launch (A/B runs)
         self.force_dp_path = False      # rehearsal hook (tools/dp_rccl_smoke.py): take the multi-rank path with one rank
         self.refresh_shadows()
 
@@ -302,7 +304,8 @@ class TrainEngine:
         for l in range(self.L):
             P = self._layer_params(l)
             h, sa = S.attn_fwd(run, h, P["ln1w"], P["ln1b"], P["wqkv"], P["wproj"], P["bproj"], True, B, T, self.NH, self.H, p, p, l)
-            h, sf = S.ffn_fwd(run, h, P["ln2w"], P["ln2b"], P["w1"], P["b1"], P["w2"], P["b2"], True, p, l)
+            h, sf = S.ffn_fwd(run, h, P["ln2w"], P["ln2b"], P["w1"], P["b1"], P["w2"], P["b2"], True, p, l,
+                              out_dtype=self.act if (l == self.L - 1 and self.last_block_act) else torch.float32)
             if want_grad:
                 saved.append((sa, sf))
         logits, (xa,) = S.linear_fwd(run, h, self.param_view("lm.w"), self.param_view("lm.b"), pad_rows=True)

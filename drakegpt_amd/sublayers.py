@@ -235,7 +235,10 @@ def attn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], wqkv: Tensor, 
 # ------------------------------------------------------------------------------------------------
 # feed-forward sub-layer
 def ffn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor], w1: Tensor, b1: Tensor,
-            w2: Optional[Tensor], b2: Optional[Tensor], residual: bool, p: float, layer: int):
+            w2: Optional[Tensor], b2: Optional[Tensor], residual: bool, p: float, layer: int,
+            out_dtype: torch.dtype = torch.float32):
+    """out_dtype: the engine asks for the activation type from the LAST block -- its output only feeds lm_head, which would
+    cast it anyway (same rounding), so the fp32 copy and the cast launch disappear."""
     if ln_w is not None:
         h, mean, rstd = ops.layernorm_fwd(x2d, ln_w, ln_b, run.act)
     else:
@@ -249,7 +252,7 @@ def ffn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor
     if ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w1.shape[1]) and ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w2.shape[0]):
         bits = ops.new_sign_bits(h.shape[0], w1.shape[0], h.device)
     f = ops.gemm_nt(h, run.weights.fwd(w1), run.act, bias=b1, relu=True, sign_bits_out=bits)
-    y = ops.gemm_nt(f, run.weights.fwd(w2), torch.float32, bias=b2, dropout_p=run.p(p), rng_state=run.rng,
+    y = ops.gemm_nt(f, run.weights.fwd(w2), out_dtype, bias=b2, dropout_p=run.p(p), rng_state=run.rng,
                     site=site_ffn(layer), residual=x2d if residual else None)
     return y, (x2d, h, mean, rstd, f, bits)
 
