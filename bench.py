@@ -197,7 +197,7 @@ def kernel_roofline(eng, offsets, peak_tflops):
             opts = [has("bias"), has("relu"), has("relu_mask"), drop, has("residual"), has("sign_bits"), has("sign_bits_out")]
             if not any(opts): epi = 1
             elif to == "bf16" and opts == [True, True, False, False, False, False, True]: epi = 2
-            elif to == "float" and opts == [True, False, False, True, True, False, False]: epi = 3
+            elif opts == [True, False, False, True, True, False, False]: epi = 3
             elif to == "bf16" and opts == [False, False, False, False, False, True, False]: epi = 6 if has("colsum_part") else 4
             elif to == "float" and opts == [True, False, False, False, False, False, False]: epi = 5
             else: epi = 0
