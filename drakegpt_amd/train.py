@@ -147,14 +147,22 @@ def main(argv=None):
     sched_steps = 0
     gen = None                       # the global CPU generator, as the reference uses
     t0 = time.perf_counter()
+    staged = None                    # engine path: the window offsets of all steps up to the next evaluation, resident in HBM
     for it in range(args.iters):
-        ix = draw_offsets(len(train_data), T, B * world, gen)
-        ix = ddist.shard_rows(ix, rank, world).to(device, non_blocking=True)
         if engine is not None:
-            engine.set_offsets(ix)
+            # same draws in the same order as one randint per step (the evaluation draws from the same generator in
+            # between, so a stage never crosses an evaluation); one upload per stage instead of one host copy per step
+            at = it % args.eval_interval
+            if at == 0:
+                n = min(args.eval_interval, args.iters - it)
+                staged = torch.stack([ddist.shard_rows(draw_offsets(len(train_data), T, B * world, gen), rank, world)
+                                      for _ in range(n)]).to(device)
+            engine.set_offsets(staged[at])
             engine.step()
         else:
             from . import ops
+            ix = draw_offsets(len(train_data), T, B * world, gen)
+            ix = ddist.shard_rows(ix, rank, world).to(device, non_blocking=True)
             x, y = ops.batch_gather(train_dev, ix, T)
             logits, loss = model(x, y)
             optimizer.zero_grad()
