@@ -13,6 +13,12 @@ dropout 0.2 (src/config.py:27-38), batch 64 per GPU, synthetic uniform char corp
 fp32 accumulation / master weights.  Inputs (corpus, window offsets) are resident in HBM when the
 timed region starts.
 
+Beside the headline line's fields the JSON carries (N = 1 only, timed AFTER the headline region, each with its own engine):
+`extra_configs` -- the same model at dropout 0 and at the largest batch (B = 256), and the GPT-2-small shape (BASELINE.json
+configs[2]: V 50257, C 768, T 1024, 12 x 12, B = 8), each as tokens/s + fraction of the bf16 MFMA peak; `hbm_kernels` -- the
+HBM-bound kernels of the step (LayerNorm fwd / bwd, cross entropy, AdamW, embedding fwd / bwd, batch gather) as achieved GB/s
+= algorithmic bytes / launch duration (HIP events, back to back), SURVEY.md section 8d.
+
 roofline: the MFMA-bound kernel symbol that takes the most time in the step; `achieved` is its
 algorithmic FLOP per launch / its average launch duration, both taken live with HIP events on the
 launch stream in an eager (un-captured) replay of the same step.  cpu_baseline: the CPU oracle
@@ -54,6 +60,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs leg (p = 0, B = 256, GPT-2-small)")
+    ap.add_argument("--dropout", type=float, default=None, help="override the preset's dropout")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,13 +93,16 @@ def main():
     from drakegpt_amd.config import DRAKE_VOCAB_SIZE, PRESETS
     from drakegpt_amd.engine import TrainEngine
 
-    cfg = PRESETS[args.config]
+    cfg = dict(PRESETS[args.config])
+    if args.dropout is not None:
+        cfg["dropout"] = args.dropout
     V = cfg.get("vocab_size", DRAKE_VOCAB_SIZE)
     B = args.batch or cfg["batch_size"]
     T = cfg["context_length"]
     torch.manual_seed(42)
     model = D.TransformerLM(V, cfg["embedding_dim"], T, cfg["num_heads"], cfg["num_layers"], cfg["dropout"],
                             precision=args.precision).to(dev)
+    n_params = sum(p.numel() for p in model.parameters())
     eng = TrainEngine(model, B, T, lr=cfg["base_lr"], betas=cfg["betas"], seed=42, rank=rank, world_size=world,
                       process_group=pg, use_graph=not args.no_graph)
     n_corpus = 1_000_000 if V <= 256 else 10_000_000
@@ -140,9 +151,23 @@ def main():
 
     if rank == 0:
         log(f"{tok_s:.0f} tokens/s, {1e3 * dt / args.steps:.3f} ms/step, loss {final_loss:.4f}")
-    roofline = None
+    roofline = hbm_kernels = None
     if rank == 0 and not args.no_kernel_timing:
-        roofline = kernel_roofline(eng, offs[0], peak)
+        roofline, hbm_kernels = kernel_roofline(eng, offs[0], peak)
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra and args.config == "scaled" and args.precision == "bf16":
+        del eng, model
+        torch.cuda.empty_cache()
+        extra = {}
+        for name, cname, b, p_drop, st, wu in (("scaled_dropout0", "scaled", B, 0.0, 30, 5), ("scaled_B256", "scaled", 256, None, 20, 5),
+                                               ("gpt2_small_B8", "gpt2_small", 8, None, 8, 3)):
+            try:
+                extra[name] = run_extra(cname, b, p_drop, st, wu, dev)
+                log(f"extra {name}: {extra[name]['value']:.0f} tokens/s, {extra[name]['ms_per_step']:.3f} ms/step")
+            except Exception as e:                     # an extra line must never take the headline line down with it
+                extra[name] = {"error": f"{type(e).__name__}: {e}"}
+                log(f"extra {name} failed: {extra[name]['error']}")
+            torch.cuda.empty_cache()
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = cpu_baseline_leg(args.config, cfg, V)
@@ -156,19 +181,60 @@ def main():
             "config": {"workload": f"TransformerLM_{args.config}: V={V} C={cfg['embedding_dim']} T={T} heads={cfg['num_heads']} "
                                    f"layers={cfg['num_layers']} dropout={cfg['dropout']}; fwd+bwd+AdamW; hipGraph={'off' if args.no_graph else 'on'}",
                        "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
-                       "params": sum(p.numel() for p in model.parameters())},
+                       "params": n_params},
             "model_flops_per_token": fpt,
             "achieved_tflops_per_gpu": tok_s * fpt / 1e12 / world,
             "mfma_peak_frac_whole_step": tok_s * fpt / 1e12 / world / peak,
             "final_loss": final_loss,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "hbm_kernels": hbm_kernels,
+            "extra_configs": extra,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
         barrier()                      # rank 0 did the kernel-timing leg: leave together
         dist.destroy_process_group()
+
+
+def run_extra(config_name, B, dropout, steps, warmup, dev):
+    """one more single-GPU configuration, timed like the headline region (offsets resident, graph replay, synchronize on
+    both sides); bf16, synthetic corpus, random-init weights (seed 42)"""
+    import drakegpt_amd as D
+    from drakegpt_amd.config import DRAKE_VOCAB_SIZE, PRESETS
+    from drakegpt_amd.engine import TrainEngine
+    cfg = dict(PRESETS[config_name])
+    if dropout is not None:
+        cfg["dropout"] = dropout
+    V = cfg.get("vocab_size", DRAKE_VOCAB_SIZE)
+    T = cfg["context_length"]
+    torch.manual_seed(42)
+    model = D.TransformerLM(V, cfg["embedding_dim"], T, cfg["num_heads"], cfg["num_layers"], cfg["dropout"], precision="bf16").to(dev)
+    eng = TrainEngine(model, B, T, lr=cfg["base_lr"], betas=cfg["betas"], seed=42)
+    n_corpus = 1_000_000 if V <= 256 else 10_000_000
+    eng.set_corpus(torch.randint(0, V, (n_corpus,), generator=torch.Generator().manual_seed(42)))
+    gen = torch.Generator().manual_seed(42)
+    offs = torch.stack([torch.randint(n_corpus - T, (B,), generator=gen) for _ in range(warmup + steps)]).to(dev)
+    for i in range(warmup):
+        eng.set_offsets(offs[i])
+        eng.step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        eng.set_offsets(offs[i])
+        eng.step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    tok_s = steps * B * T / dt
+    fpt = flops_per_token(cfg, V)
+    loss = eng.loss.item()
+    del eng, model
+    return {"value": tok_s, "unit": "tokens/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+            "workload": f"TransformerLM_{config_name}: V={V} C={cfg['embedding_dim']} T={T} heads={cfg['num_heads']} layers={cfg['num_layers']} "
+                        f"dropout={cfg['dropout']} batch={B}; fwd+bwd+AdamW; bf16; hipGraph=on",
+            "model_flops_per_token": fpt, "achieved_tflops": tok_s * fpt / 1e12,
+            "mfma_peak_frac_whole_step": tok_s * fpt / 1e12 / PEAK_BF16_TFLOPS, "final_loss": loss}
 
 
 def kernel_roofline(eng, offsets, peak_tflops):
@@ -225,14 +291,65 @@ def kernel_roofline(eng, offsets, peak_tflops):
         sym = "gemm_tn_grouped_kernel" if os.environ.get("DG_TN_TILE") == "128" else "gemm_tn_grouped256_kernel"
         calls.append((sym, fl, lambda: real_tng(problems, workspace)))
 
+    # HBM-bound kernels: algorithmic bytes per launch (what the kernel must read + write once; SURVEY 8d conventions)
+    hbm = []              # (symbol, bytes, closure)
+    esz = lambda t: t.element_size()
+    hbm_names = ("layernorm_fwd", "layernorm_bwd_fused", "layernorm_bwd", "cross_entropy", "adamw_step", "embed_fwd", "embed_bwd",
+                 "batch_gather")
+    real_hbm = {n: getattr(ops, n) for n in hbm_names}
+
+    def wrap(name, nbytes):
+        real = real_hbm[name]
+
+        def f(*a, **kw):
+            r = real(*a, **kw)
+            hbm.append((name, float(nbytes(r, *a, **kw)), lambda: real(*a, **kw)))
+            return r
+        return f
+    wrapped = {
+        # x fp32 in, y out (+ mean, rstd)
+        "layernorm_fwd": wrap("layernorm_fwd", lambda r, x, g, b, od, *a, **k: x.numel() * (4 + esz(r[0])) + 8 * r[1].numel()),
+        # dy, x, dresid in; dx (+ g) out
+        "layernorm_bwd_fused": wrap("layernorm_bwd_fused", lambda r, dy, x, *a, **k: x.numel() * (esz(dy) + 4 + (4 if a[3] is not None else 0) + 4 + esz(r[1]))),
+        "layernorm_bwd": wrap("layernorm_bwd", lambda r, dy, x, g, mean, rstd, dresid, *a, **k: x.numel() * (esz(dy) + 4 + (4 if dresid is not None else 0) + 4)),
+        # logits in, dlogits out
+        "cross_entropy": wrap("cross_entropy", lambda r, logits, tg, V, dlogits=None, **k: logits.shape[0] * V * 4 + (dlogits.numel() * esz(dlogits) if dlogits is not None else 0)),
+        # p, g, m, v read; p, m, v (+ bf16 shadow) written
+        "adamw_step": wrap("adamw_step", lambda r, p, g, m, v, hy, st, gs=1.0, shadow_bf16=None, n=None: (n or p.numel()) * (28 + (2 if shadow_bf16 is not None else 0))),
+        "embed_fwd": wrap("embed_fwd", lambda r, idx, tok, pos, out=None, onehot=None: r.numel() * 4 + idx.numel() * 8 + (onehot.numel() * 2 if onehot is not None else 0)),
+        "embed_bwd": wrap("embed_bwd", lambda r, idx, dx, dtok, dpos, V=None: dx.numel() * 4 + (dpos.numel() * 4 if dpos is not None else 0) + (dtok.numel() * 4 if dtok is not None else 0)),
+        "batch_gather": wrap("batch_gather", lambda r, corpus, offsets, T, x=None, y=None: offsets.numel() * T * 32),
+    }
     eng.set_offsets(offsets)
     ops.gemm_nt, ops.gemm_tn, ops.gemm_tn_grouped = nt, tn, tng
+    for n_, f_ in wrapped.items():
+        setattr(ops, n_, f_)
     try:
         eng._prog_fwd_bwd()
         eng._prog_update()
         torch.cuda.synchronize()
     finally:
         ops.gemm_nt, ops.gemm_tn, ops.gemm_tn_grouped = real_nt, real_tn, real_tng
+        for n_, f_ in real_hbm.items():
+            setattr(ops, n_, f_)
+    snap = (eng.flat.clone(), eng.m_.clone(), eng.v_.clone())       # the AdamW replays below must not train the model away
+    hagg = {}
+    for sym, nb, fn in hbm:
+        fn(); fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            fn()
+        e.record()
+        e.synchronize()
+        a = hagg.setdefault(sym, [0.0, 0.0, 0])
+        a[0] += nb
+        a[1] += s.elapsed_time(e) * 1e-3 / 10
+        a[2] += 1
+    eng.flat.copy_(snap[0]); eng.m_.copy_(snap[1]); eng.v_.copy_(snap[2])
+    eng.refresh_shadows()
+    hbm_kernels = {k: {"achieved_GBs": v[0] / v[1] / 1e9, "frac_of_8TBs": v[0] / v[1] / 1e9 / PEAK_HBM_GBS, "avg_us": 1e6 * v[1] / v[2],
+                       "launches_per_step": v[2], "algorithmic_bytes_per_launch": v[0] / v[2]} for k, v in hagg.items()}
     reps = 10
     agg = {}
     for sym, fl, fn in calls:
@@ -259,7 +376,7 @@ def kernel_roofline(eng, offsets, peak_tflops):
             "frac": achieved / peak_tflops, "traffic": traffic, "launches_per_step": n,
             "avg_launch_us": 1e6 * sec / n, "flops_per_launch": fl / n,
             "all_gemm_symbols": {k: {"tflops": v[0] / v[1] / 1e12, "avg_us": 1e6 * v[1] / v[2], "launches_per_step": v[2]}
-                                 for k, v in agg.items()}}
+                                 for k, v in agg.items()}}, hbm_kernels
 
 
 def usable_cores() -> int:
@@ -295,7 +412,7 @@ def cpu_baseline_leg(config_name, cfg, V):
     ncores = usable_cores()
     torch.set_num_threads(ncores)
     log(f"cpu baseline on {ncores} threads")
-    B = 8 if cfg["embedding_dim"] >= 256 else cfg["batch_size"]
+    B = cfg["batch_size"]                  # the configuration's own batch ("configs 1-2 in full")
     T = cfg["context_length"]
     ocfg = dict(cfg)
     sd = R.init_state_dict("TransformerLM", V, ocfg, seed=42)
@@ -311,10 +428,9 @@ def cpu_baseline_leg(config_name, cfg, V):
         R.train_step("TransformerLM", sd, opt, x, y, p=cfg["dropout"], training=True)
         steps += 1
         el = time.perf_counter() - t0
-        if el > 12.0 or steps >= 200:
+        log(f"cpu baseline: {steps} steps, {el:.1f} s")
+        if (el > 12.0 and steps >= 2) or steps >= 200:
             break
-        if steps % 2 == 0:
-            log(f"cpu baseline: {steps} steps, {el:.1f} s")
     return {"value": steps * B * T / el, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} fwd+bwd+AdamW steps of TransformerLM_{config_name} at batch {B} x {T} tokens, fp32 torch CPU ops "
                       f"(oracle/drake_ref.py, bit-identical to the reference), {el:.1f} s"}

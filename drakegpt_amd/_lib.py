@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdrakegpt_hip.so")
 
 DG_F32 = 0
 DG_BF16 = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GemmNtArgs(C.Structure):

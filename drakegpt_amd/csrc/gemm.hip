@@ -1066,7 +1066,7 @@ struct TnProblem {
     int P, Q, R, tiles_q, tile_begin;
 };
 // ws (256-row-tile kernel only): split-K workspace, [total_tiles][8 waves][16 KB] fp32 partials then [total_tiles][8] flags
-struct TnGroup { int n, total_tiles; int splits, tiles_pad; char* ws; TnProblem pr[TN_MAX_GROUP]; };
+struct TnGroup { int n, total_tiles; int splits, tiles_pad; char* ws; unsigned* err; TnProblem pr[TN_MAX_GROUP]; };
 
 __global__ __launch_bounds__(768) void gemm_tn_grouped_kernel(TnGroup gp) {
     __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE];
@@ -1389,7 +1389,13 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
                     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 return;
             }
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+            // Bounded wait (~1 s): the producer is an earlier item of a LOWER-numbered workgroup that never waits itself (see the
+            // launch rules in dg_gemm_tn_grouped), so under in-order dispatch this resolves in microseconds.  If it ever does
+            // not (CU mask, a broken build), give up instead of hanging the GPU: the sticky error word marks the result invalid.
+            for (unsigned spin = 0; __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++spin) {
+                if (spin >= (1u << 22)) { if (lane == 0) __hip_atomic_store(gp.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             f32x4 t[16];
 #pragma unroll
@@ -1588,7 +1594,7 @@ extern "C" int64_t dg_gemm_tn_grouped_workspace_bytes(const dg_tn_problem* probl
         const int64_t t = tn_group_tiles(problems + base, n - base < TN_MAX_GROUP ? n - base : TN_MAX_GROUP);
         if (t > most) most = t;
     }
-    return most * (8 * 16384 + 8 * 4);
+    return most * (8 * 16384 + 8 * 4) + 16;       // + the sticky error word (last 16 bytes)
 }
 
 extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtype, void* workspace, int64_t workspace_bytes,
@@ -1628,12 +1634,17 @@ extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtyp
         gp.tiles_pad = (tiles + 7) / 8 * 8;
         gp.splits = 1;
         gp.ws = nullptr;
+        gp.err = workspace ? (unsigned*)((char*)workspace + dg_gemm_tn_grouped_workspace_bytes(problems, n) - 16) : nullptr;
         const int ncu = dg_num_cus();
         if (tile_p == 256 && workspace && split_mode && nk_min >= 2) {
             // two K halves per tile when that shortens the schedule: rounds x steps per round
             const int64_t whole = (int64_t)((tiles + ncu - 1) / ncu) * nk_max;
             const int64_t halves = (int64_t)((2 * gp.tiles_pad + ncu - 1) / ncu) * ((nk_max + 1) / 2);
-            if (halves < whole) { gp.splits = 2; gp.ws = (char*)workspace; }
+            // Cutting EVERY tile is only taken when each workgroup gets one item (2 tiles_pad <= #CUs): the second half of tile t
+            // (workgroup tiles_pad + t) then waits for workgroup t, a lower-numbered one that never waits -- safe whatever part of
+            // the grid is resident.  With several items per workgroup the second halves of tiles [G - tiles_pad % G, G) would sit
+            // on LOWER-numbered workgroups than their producers: a deadlock as soon as fewer than G workgroups are resident.
+            if (halves < whole && 2 * gp.tiles_pad <= ncu) { gp.splits = 2; gp.ws = (char*)workspace; }
             // cut only the leftover tiles when their halves fit into one half round (see the kernel)
             static const int lo_mode = [] { const char* e = getenv("DG_TN_LEFTOVER"); return e ? atoi(e) : 1; }();   // 0 = cut every tile (A/B runs)
             const int r = tiles % ncu;

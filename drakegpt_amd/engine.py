@@ -159,6 +159,8 @@ class TrainEngine:
         import os
         self.last_block_act = os.environ.get("DG_LAST_BLOCK_ACT", "1") != "0"      # 0: fp32 output + cast launch (A/B runs)
         self.force_dp_path = False      # rehearsal hook (tools/dp_rccl_smoke.py): take the multi-rank path with one rank
+        self.keep_logits = False        # parity tests: keep the step's logits [M, V] alive as `last_logits` (also inside a captured graph)
+        self.last_logits: Optional[Tensor] = None
         self.refresh_shadows()
 
     # -------------------------------------------------------------------------------- layout
@@ -206,6 +208,28 @@ class TrainEngine:
         for d in shape:
             n *= d
         return self.gflat[off:off + n].view(shape)
+
+    def named_grads(self) -> Dict[str, Tensor]:
+        """the step's gradient as views of the flat buffer, keyed by the reference's parameter names (what `p.grad` holds after
+        `loss.backward()` in ref: src/train.py:150; after a data-parallel step: the SUM over ranks).  `ln_f.*` is absent: it never
+        receives a gradient."""
+        NH, H = self.NH, self.H
+        out: Dict[str, Tensor] = {}
+        for l in range(self.L):
+            wqkv = self.grad_view(f"{l}.wqkv")
+            pre = f"blocks.{l}."
+            for h in range(NH):
+                out[f"{pre}sa_head.heads.{h}.key.weight"] = wqkv[(NH + h) * H:(NH + h + 1) * H]
+                out[f"{pre}sa_head.heads.{h}.query.weight"] = wqkv[h * H:(h + 1) * H]
+                out[f"{pre}sa_head.heads.{h}.value.weight"] = wqkv[(2 * NH + h) * H:(2 * NH + h + 1) * H]
+            for ref, key in (("sa_head.proj.weight", "wproj"), ("sa_head.proj.bias", "bproj"), ("ffwd.net.0.weight", "w1"),
+                             ("ffwd.net.0.bias", "b1"), ("ffwd.net.2.weight", "w2"), ("ffwd.net.2.bias", "b2"),
+                             ("ln1.weight", "ln1w"), ("ln1.bias", "ln1b"), ("ln2.weight", "ln2w"), ("ln2.bias", "ln2b")):
+                out[pre + ref] = self.grad_view(f"{l}.{key}")
+        out["lm_head.weight"], out["lm_head.bias"] = self.grad_view("lm.w"), self.grad_view("lm.b")
+        out["token_embedding_table.weight"] = self.grad_view("tok")
+        out["position_embedding_table.weight"] = self.grad_view("pos")
+        return out
 
     def _alloc_and_adopt(self):
         """copy the model's current weights into the flat buffer and re-point its Parameters at it"""
@@ -360,7 +384,9 @@ class TrainEngine:
         if self.corpus is not None:
             ops.batch_gather(self.corpus, self.offsets, self.T, self.x, self.y)
         run = S.Run(act=self.act, rng=self.state if self.p_drop > 0.0 else None, weights=self.weights)
-        _, rows, ctx = self._forward(run, self.x, self.y, True)
+        logits, rows, ctx = self._forward(run, self.x, self.y, True)
+        if self.keep_logits:
+            self.last_logits = logits
         ops.reduce_sum(rows, 1.0 / self.M, out=self.loss)
         self._backward(run, self.x, ctx)
 
@@ -408,7 +434,10 @@ class TrainEngine:
     # -------------------------------------------------------------------------------- public
     def set_corpus(self, data: Tensor):
         """keep the token stream resident in HBM (int64, as train_data.pt stores it)"""
+        if data.dim() != 1 or data.numel() < self.T + 1:
+            raise ValueError(f"set_corpus: need a 1-D token stream of more than context_length = {self.T} tokens")
         self.corpus = data.to(self.dev, dtype=torch.int64).contiguous()
+        ops.check_ids(self.corpus, self.V, "the corpus")          # once, here: the captured step never checks
         self._graphs = None
 
     def set_lr(self, lr: float):
@@ -417,11 +446,23 @@ class TrainEngine:
     def set_offsets(self, ix: Tensor):
         """window offsets of THIS rank's rows (drawn by the host CPU generator, ref: preprocessing.py:43)"""
         if ix.is_cuda:
-            self.offsets.copy_(ix, non_blocking=True)      # stream-ordered device copy
+            self.offsets.copy_(ix, non_blocking=True)      # stream-ordered device copy (range-checked where they were staged)
         else:
+            self.check_offsets(ix)
             self.offsets.copy_(ix)                         # synchronous: stage blocks of offsets in HBM instead
 
+    def check_offsets(self, ix: Tensor):
+        """window offsets must leave room for T + 1 tokens (ref: randint(len(data) - context_length), src/preprocessing.py:43);
+        host tensors are checked for free, device tensors cost one round trip: check a staged block once, not every step"""
+        if self.corpus is not None and ix.numel():
+            lo, hi = (int(v) for v in torch.aminmax(ix))
+            if lo < 0 or hi + self.T + 1 > self.corpus.numel():
+                raise IndexError(f"window offsets in [{lo}, {hi}] do not fit a corpus of {self.corpus.numel()} tokens at T = {self.T}")
+
     def set_batch(self, x: Tensor, y: Tensor):
+        """token / target ids of this rank's rows, given directly (ids are validated here; the captured step never checks)"""
+        ops.check_ids(x, self.V, "x")
+        ops.check_ids(y, self.V, "y")
         self.x.copy_(x, non_blocking=True)
         self.y.copy_(y, non_blocking=True)
 
@@ -488,6 +529,12 @@ class TrainEngine:
             self._eval_graph.replay()
             out[i:i + 1].copy_(self.ev_loss)
         return out
+
+    def check_status(self) -> None:
+        """raise if a bounded device-side wait of the grouped dW GEMM ever ran out (dg_gemm_tn_grouped: the sticky error word in
+        the last 16 bytes of its workspace).  One device round trip: for tests / end-of-run checks, not for every step."""
+        if self.tn_workspace is not None and int(self.tn_workspace[-16:].view(torch.int32)[0].item()) != 0:
+            raise RuntimeError("dg_gemm_tn_grouped: a split-K hand-over timed out; weight gradients since then are invalid")
 
     def step_count(self) -> int:
         return int(self.state[2].item())

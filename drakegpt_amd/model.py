@@ -8,9 +8,13 @@ Reference quirks kept on purpose:
   * TransformerLM owns ``ln_f`` but never applies it (src/model.py:572,598-599): the parameters
     exist in the state_dict, take no part in compute and never receive a gradient;
   * MultiHeadAttentionLM's per-head size is head_size // num_heads (src/model.py:264);
-  * generate() re-runs the full forward per token without a KV cache and crops to context_length
-    (src/model.py:625); sampling draws from torch's CPU generator so that, given matching logits,
-    the sampled indices are bit-identical to the reference run on CPU.
+  * generate() crops to context_length (src/model.py:625) and samples from torch's CPU generator so that, given
+    matching logits, the sampled indices are bit-identical to the reference run on CPU.  The five earlier-stage
+    models re-run the full forward per token as the reference does; TransformerLM.generate keeps a K/V cache while
+    the sequence fits the context window (same logits, see its docstring) and falls back to the reference
+    algorithm once the window slides;
+  * token / target ids outside [0, vocab_size) raise IndexError at the module boundary, as nn.Embedding and
+    F.cross_entropy do in the reference (the kernels themselves clamp and never fault).
 """
 from __future__ import annotations
 
@@ -65,9 +69,18 @@ class _LM(HipModule):
     def _head(self, x):
         return HF.linear(x, self.lm_head.weight, self.lm_head.bias, self.act_dtype)
 
+    def _check_ids(self, idx, targets):
+        ops._chk(idx, "idx", torch.int64, contiguous=False)
+        V = self.token_embedding_table.weight.shape[0]
+        ops.check_ids(idx, V, "idx")
+        if targets is not None:
+            ops._chk(targets, "targets", torch.int64, contiguous=False)
+            ops.check_ids(targets, V if not hasattr(self, "lm_head") else self.lm_head.weight.shape[0], "targets")
+
     def forward(self, idx, targets=None):
         if idx.dim() != 2:
             raise ValueError("idx must be (B, T)")
+        self._check_ids(idx, targets)
         rng = self._rng_snapshot(idx.device, self._any_dropout())
         logits = self._head(self._body(self._embed(idx), rng))
         if targets is None:
@@ -102,6 +115,7 @@ class BigramLM(_LM):
         self.token_embedding_table = nn.Embedding(vocab_size, vocab_size)
 
     def forward(self, idx, targets=None):
+        self._check_ids(idx, targets)
         logits = HF.embed(idx, self.token_embedding_table.weight, None)
         if targets is None:
             return logits, None
@@ -233,6 +247,7 @@ class TransformerLM(_BlocksLM):
         if not use_cache or self.training or idx.shape[1] >= self.context_length:
             return super().generate(idx, max_new_tokens, generator)
         B, t0 = idx.shape
+        self._check_ids(idx, None)
         C3 = 3 * self.token_embedding_table.weight.shape[1]
         ws, w_lm = self._decode_weights()
         caches = [torch.zeros((B, self.context_length, C3), dtype=self.act_dtype, device=idx.device) for _ in self.blocks]

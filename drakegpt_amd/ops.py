@@ -52,6 +52,19 @@ def _ld(t: Tensor) -> int:
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
+def check_ids(ids: Tensor, n: int, what: str) -> None:
+    """raise IndexError unless 0 <= ids < n -- what nn.Embedding / F.cross_entropy do in the reference (ref: src/model.py:595,
+    606).  The kernels clamp ids so that a bad one can never fault the GPU, which would otherwise turn a tokenizer / vocabulary
+    mismatch into a plausible loss on aliased ids.  One device round trip: call it where ids ENTER (module forward, set_corpus,
+    set_batch), never inside a captured step."""
+    if ids.numel() == 0:
+        return
+    lo, hi = torch.aminmax(ids)
+    lo, hi = int(lo), int(hi)
+    if lo < 0 or hi >= n:
+        raise IndexError(f"index out of range in self: {what} holds ids in [{lo}, {hi}], valid range is [0, {n})")
+
+
 # ------------------------------------------------------------------------------------------
 def new_rng_state(seed: int, device, step: int = 0) -> Tensor:
     """device uint32[4] = {seed_lo, seed_hi, step, 0} (stored as int32 bit patterns)."""

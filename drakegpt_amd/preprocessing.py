@@ -56,3 +56,39 @@ def encode_text(text: str):
     (ref: src/preprocessing.py:68-73)."""
     encode, decode, vocab_size = get_mapper(text)
     return torch.tensor(encode(text), dtype=torch.long), decode, vocab_size
+
+
+def get_train_val_data(input_path: str, train_path: str, val_path: str, verbose: bool = True):
+    """ref: src/preprocessing.py:48-86 -- read the text, build the char mapper, encode to int64, split 90/10 and save the two
+    token streams with ``torch.save`` as bare tensors: the on-disk ``train_data.pt`` / ``val_data.pt`` format that
+    src/train.py:94-98 loads (and ``load_train_val_data`` below reads back with ``weights_only=True``).  Also prints the
+    reference's example batch (4 windows of 8 tokens, seed 42) -- drawn by plain host indexing: this is file preparation, it
+    needs no GPU.  Returns (train_data, val_data, vocab_size)."""
+    torch.manual_seed(42)
+    with open(input_path, "r", encoding="utf-8") as f:
+        text = f.read()
+    encode, decode, vocab_size = get_mapper(text)
+    data = torch.tensor(encode(text), dtype=torch.long)
+    train_data, val_data = split_train_val(data)
+    if verbose:
+        print(f"Vocab size of the text: {vocab_size}")
+        if len(train_data) > 9:
+            ix = draw_offsets(len(train_data), 8, 4)
+            x0, y0 = train_data[ix[0]:ix[0] + 8].tolist(), train_data[ix[0] + 1:ix[0] + 9].tolist()
+            print(f"Input (encoded):\n{x0}\nInput (decoded):\n{decode(x0)}\nOutput (encoded):\n{y0}\nOutput (decoded):\n{decode(y0)}\n")
+    torch.save(train_data.clone(), train_path)        # clone: a view would drag the whole corpus into each file
+    torch.save(val_data.clone(), val_path)
+    return train_data, val_data, vocab_size
+
+
+def load_train_val_data(train_path: str, val_path: str):
+    """the two token streams get_train_val_data (or the reference's src/preprocessing.py) wrote -- ref: src/train.py:97-98.
+    Loaded with ``weights_only=True`` (nothing in the file is executed); must be 1-D int64."""
+    out = []
+    for path in (train_path, val_path):
+        t = torch.load(path, map_location="cpu", weights_only=True)
+        if not isinstance(t, torch.Tensor) or t.dim() != 1 or t.dtype != torch.int64:
+            raise ValueError(f"{path}: expected a 1-D int64 token tensor (train_data.pt / val_data.pt format), got "
+                             f"{type(t).__name__} {getattr(t, 'dtype', '')} {tuple(getattr(t, 'shape', ()))}")
+        out.append(t.contiguous())
+    return out[0], out[1]

@@ -3,6 +3,11 @@
     python -m drakegpt_amd.train --model TransformerLM --scale --data path/to/text.txt [--iters N]
     python -m torch.distributed.run --nproc-per-node 8 -m drakegpt_amd.train --model TransformerLM --scale ...
 
+Data parallel semantics (weak scaling, as BASELINE.json configs[3] "global batch = 8 x local"): every rank trains the preset's
+batch_size rows, the global batch is batch_size * world_size drawn by ONE seeded CPU generator (every rank draws all of it and
+keeps its rows), the gradient is the mean over the global batch, and the learning rate is NOT rescaled -- the reference has a
+single fixed batch of batch_size rows, so a world_size > 1 run is a different (larger-batch) optimisation problem by design.
+
 Kept from the reference (src/train.py): build_model's per-model constructor arguments (:31-57),
 evaluate_loss (eval mode, mean of eval_iters batch losses on train and val, :61-75), get_model_path
 naming (:77-83), AdamW(lr=base_lr, betas) (:121), CyclicLR(base_lr, max_lr, step_size_up=5,
@@ -27,7 +32,7 @@ import torch
 from . import dist as ddist
 from .config import DRAKE_VOCAB_SIZE, PARAMS, PRESETS, SCALE_PARAMS, TRAIN
 from .model import MODEL_CLASSES, model_params
-from .preprocessing import draw_offsets, encode_text, split_train_val
+from .preprocessing import draw_offsets, encode_text, get_mapper, load_train_val_data, split_train_val
 
 
 def build_model(model_name: str, scale: bool, params: dict, scale_params: dict, vocab_size: int, device, precision: str = "fp32"):
@@ -89,13 +94,39 @@ def evaluate_loss(train_data, val_data, model, eval_iters, context_length, batch
     return out
 
 
+def engine_loop(engine, n_train: int, T: int, B: int, rank: int, world: int, iters: int, eval_interval: int, on_eval, device,
+                generator: Optional[torch.Generator] = None) -> None:
+    """The training iterations of ref: src/train.py:141-172 on the engine path.  The reference draws one randint(len(data) - T,
+    (B,)) per step from the global CPU generator and, every eval_interval steps, 2 * eval_iters more inside evaluate_loss --
+    the SAME generator.  Here the offsets of all steps up to the next evaluation are drawn in one go (same draws, same order:
+    a stage never crosses an evaluation) and uploaded once, so a step is one 8*B-byte device copy + one graph launch.
+    `on_eval(it)` runs after step `it` when (it + 1) % eval_interval == 0."""
+    staged = None
+    for it in range(iters):
+        at = it % eval_interval
+        if at == 0:
+            n = min(eval_interval, iters - it)
+            staged = torch.stack([ddist.shard_rows(draw_offsets(n_train, T, B * world, generator), rank, world) for _ in range(n)])
+            engine.check_offsets(staged)
+            staged = staged.to(device)
+        engine.set_offsets(staged[at])
+        engine.step()
+        if (it + 1) % eval_interval == 0:
+            on_eval(it)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="Train a DrakeGPT language model on MI355X")
     ap.add_argument("--model", default="TransformerLM", choices=list(MODEL_CLASSES))
     ap.add_argument("--scale", action="store_true", help="use SCALE_PARAMS (ref: --scale True)")
-    ap.add_argument("--preset", default=None, choices=list(PRESETS), help="overrides --scale")
+    ap.add_argument("--preset", default=None, choices=list(PRESETS), help="overrides --scale.  Under torch.distributed.run the "
+                    "preset's batch_size is PER RANK (global batch = batch_size * world_size, learning rate unchanged)")
     ap.add_argument("--no-save", action="store_true")
-    ap.add_argument("--data", default=None, help="UTF-8 text file (the reference's data/Drake_lyrics.txt)")
+    ap.add_argument("--data", default=None, help="UTF-8 text file (the reference's data/input.txt): tokenised and split 90/10 on "
+                    "the fly, or -- with --train-data/--val-data -- only the source of the char mapper (ref: src/train.py:94-100)")
+    ap.add_argument("--train-data", default=None, help="train_data.pt written by drakegpt_amd.preprocessing.get_train_val_data "
+                    "(or the reference's src/preprocessing.py): 1-D int64 token tensor")
+    ap.add_argument("--val-data", default=None, help="val_data.pt, same format")
     ap.add_argument("--iters", type=int, default=TRAIN["iters"])
     ap.add_argument("--eval-interval", type=int, default=TRAIN["eval_interval"])
     ap.add_argument("--eval-iters", type=int, default=TRAIN["eval_iters"])
@@ -112,15 +143,26 @@ def main(argv=None):
     device = torch.device("cuda", local_rank)
     pg = ddist.init("nccl", device)
 
-    if args.data:
+    if bool(args.train_data) != bool(args.val_data):
+        raise SystemExit("--train-data and --val-data go together")
+    decode = lambda ids: " ".join(str(i) for i in ids)      # noqa: E731
+    if args.train_data:
+        # the reference's flow (src/train.py:94-100): token streams from the .pt files, the mapper from the text
+        train_data, val_data = load_train_val_data(args.train_data, args.val_data)
+        if args.data:
+            with open(args.data, "r", encoding="utf-8") as f:
+                _, decode, vocab_size = get_mapper(f.read())
+        else:
+            vocab_size = int(max(train_data.max(), val_data.max())) + 1
+    elif args.data:
         with open(args.data, "r", encoding="utf-8") as f:
             text = f.read()
         data, decode, vocab_size = encode_text(text)
+        train_data, val_data = split_train_val(data)
     else:
         vocab_size = DRAKE_VOCAB_SIZE
         data = torch.randint(0, vocab_size, (1_000_000,), generator=torch.Generator().manual_seed(42))
-        decode = lambda ids: " ".join(str(i) for i in ids)      # noqa: E731
-    train_data, val_data = split_train_val(data)
+        train_data, val_data = split_train_val(data)
     train_dev, val_dev = train_data.to(device), val_data.to(device)
 
     params = PRESETS[args.preset] if args.preset else (SCALE_PARAMS if args.scale else PARAMS)
@@ -144,45 +186,38 @@ def main(argv=None):
         optimizer = AdamW(model.parameters(), lr=base_lr, betas=params["betas"])
 
     model.train()
-    sched_steps = 0
-    gen = None                       # the global CPU generator, as the reference uses
+    sched = {"steps": 0}
     t0 = time.perf_counter()
-    staged = None                    # engine path: the window offsets of all steps up to the next evaluation, resident in HBM
-    for it in range(args.iters):
+
+    def on_eval(it):
+        model.eval()
+        losses = evaluate_loss(train_dev, val_dev, model, args.eval_iters, T, B, device, engine=engine)
+        sched["steps"] += 1
+        lr = cyclic_lr(sched["steps"], base_lr, max_lr)
         if engine is not None:
-            # same draws in the same order as one randint per step (the evaluation draws from the same generator in
-            # between, so a stage never crosses an evaluation); one upload per stage instead of one host copy per step
-            at = it % args.eval_interval
-            if at == 0:
-                n = min(args.eval_interval, args.iters - it)
-                staged = torch.stack([ddist.shard_rows(draw_offsets(len(train_data), T, B * world, gen), rank, world)
-                                      for _ in range(n)]).to(device)
-            engine.set_offsets(staged[at])
-            engine.step()
+            engine.set_lr(lr)
         else:
-            from . import ops
-            ix = draw_offsets(len(train_data), T, B * world, gen)
-            ix = ddist.shard_rows(ix, rank, world).to(device, non_blocking=True)
+            for g in optimizer.param_groups:
+                g["lr"] = lr
+        if rank == 0:
+            el = time.perf_counter() - t0
+            print(json.dumps({"step": it + 1, "train_loss": float(losses["train"]), "val_loss": float(losses["val"]), "lr": lr,
+                              "tokens_per_s": (it + 1) * B * T * world / el}), flush=True)
+        model.train()
+
+    if engine is not None:
+        engine_loop(engine, len(train_data), T, B, rank, world, args.iters, args.eval_interval, on_eval, device)
+    else:
+        from . import ops
+        for it in range(args.iters):
+            ix = draw_offsets(len(train_data), T, B, None).to(device, non_blocking=True)
             x, y = ops.batch_gather(train_dev, ix, T)
             logits, loss = model(x, y)
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()
-        if (it + 1) % args.eval_interval == 0:
-            model.eval()
-            losses = evaluate_loss(train_dev, val_dev, model, args.eval_iters, T, B, device, engine=engine)
-            sched_steps += 1
-            lr = cyclic_lr(sched_steps, base_lr, max_lr)
-            if engine is not None:
-                engine.set_lr(lr)
-            else:
-                for g in optimizer.param_groups:
-                    g["lr"] = lr
-            if rank == 0:
-                el = time.perf_counter() - t0
-                print(json.dumps({"step": it + 1, "train_loss": float(losses["train"]), "val_loss": float(losses["val"]), "lr": lr,
-                                  "tokens_per_s": (it + 1) * B * T * world / el}), flush=True)
-            model.train()
+            if (it + 1) % args.eval_interval == 0:
+                on_eval(it)
 
     model.eval()
     if rank == 0:

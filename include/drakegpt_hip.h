@@ -42,7 +42,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 3   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 4   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -60,8 +60,9 @@ int dg_batch_gather(const int64_t* corpus, int64_t n_corpus, const int64_t* offs
 /* ---------------------------------------------------------------------------------------
  * Token + position embedding -- ref: src/model.py:595-597 (K1-K3).
  * x[b,t,:] = tok[idx[b,t],:] + pos[t,:]   (pos == NULL: BigramLM-style plain gather, :96).
- * Returns DG_ERR_ARG if T > rows of pos is the caller's job to check; idx values are clamped
- * to [0, V) on the device (torch would raise; the Python layer checks in debug mode). */
+ * T <= rows of pos is the caller's job to check.  idx values are clamped to [0, V) on the device so that a bad id can
+ * never fault the GPU; torch raises IndexError instead, and so does the Python layer, at the points where ids enter
+ * (drakegpt_amd.ops.check_ids: module forward / generate, TrainEngine.set_corpus / set_batch) -- never inside the step. */
 int dg_embed_fwd(const int64_t* idx, const float* tok, const float* pos, float* x,
                  int B, int T, int C, int V, void* onehot, int64_t ld_onehot, void* stream);
 /* onehot (nullable): bf16 [B*T, ld_onehot >= V, multiple of 8], row m = e_{idx[m]}.  With it the token-table gradient
@@ -173,10 +174,13 @@ int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtype, void* wo
  * caller and then left to the library between calls on one stream): lets the kernel cut every tile's contraction into
  * two halves run by different workgroups when that shortens the schedule (381 tiles on 256 CUs: 3 rounds of half
  * tiles instead of 2 rounds of whole ones).  The halves are summed first + second, a fixed order.  NULL = no split.
- * The second half of a tile waits (spins on a flag) for the first half, which an earlier-numbered work item of another
- * workgroup computes: the launch uses at most one workgroup per CU and every workgroup takes its items in increasing order,
- * so the wait always resolves as long as workgroups that finish make room for the not-yet-resident ones (normal dispatch;
- * do not run it under a CU mask smaller than half the device). */
+ * A second half waits (spins on a flag) for the first half of its tile.  The launch rules make the producer an earlier item
+ * of a LOWER-numbered workgroup that never waits itself: every tile is cut only when each workgroup gets one item (2 * tiles
+ * <= #CUs: workgroup tiles + t waits for workgroup t); otherwise only the leftover tiles of the last round are cut, their
+ * first halves run FIRST on even XCDs and their second halves LAST on the next-numbered workgroup.  Under in-order workgroup
+ * dispatch the wait therefore resolves whatever part of the grid is resident.  It is bounded all the same (~1 s): a wave
+ * that runs out sets the sticky error word in the LAST 16 BYTES of the workspace (uint32, non-zero = some result of some
+ * launch since the workspace was zeroed is invalid) instead of hanging the GPU; the host may read it at any sync point. */
 int64_t dg_gemm_tn_grouped_workspace_bytes(const dg_tn_problem* problems, int n);
 
 /* out[i] = sum_{g < n_partials} partials[g*stride + i], i < n.  Deterministic order. */

@@ -58,23 +58,51 @@ def _drop(x: Tensor, p: float, training: bool, mask: Optional[Tensor]) -> Tensor
     return F.dropout(x, p, training)
 
 
+# --------------------------------------------------------------------------------------
+# rounding model of the kernels' bf16 mode (NOT reference arithmetic: the reference is fp32 only)
+# --------------------------------------------------------------------------------------
+class _RoundGrad(torch.autograd.Function):
+    """identity in forward; the gradient is rounded to bf16 on its way back -- the places where the HIP path
+    stores a gradient as a bf16 GEMM operand while the forward value stays fp32 (dropout-backward of the proj /
+    FeedForward outputs, dlogits, dS)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _rb(x: Tensor, on: bool) -> Tensor:
+    """value AND gradient rounded to bf16 (autograd of the cast pair rounds the gradient too): the places where the
+    HIP path stores an activation as bf16 (LayerNorm output, q/k/v, dropped-out probabilities, attention output,
+    FeedForward hidden layer, lm_head input, bf16 weight copies)."""
+    return x.bfloat16().float() if on else x
+
+
+def _rg(x: Tensor, on: bool) -> Tensor:
+    return _RoundGrad.apply(x) if on else x
+
+
 def head_forward(sd: SD, prefix: str, x: Tensor, p: float = 0.0, training: bool = False,
-                 mask: Optional[Tensor] = None) -> Tensor:
+                 mask: Optional[Tensor] = None, bf16: bool = False) -> Tensor:
     """One causal attention head. ref: Head.forward src/model_component.py:40-66,
     Head2.forward :378-407 (same math; Head2 adds dropout on the probabilities)."""
     wk, wq, wv = sd[prefix + "key.weight"], sd[prefix + "query.weight"], sd[prefix + "value.weight"]
     T = x.shape[1]
     hs = wk.shape[0]
-    k = F.linear(x, wk)                                    # mc:392
-    q = F.linear(x, wq)                                    # mc:393
-    w = q @ k.transpose(-2, -1) * hs ** -0.5               # mc:396 (scale after the matmul)
+    k = _rb(F.linear(x, _rb(wk, bf16)), bf16)              # mc:392
+    q = _rb(F.linear(x, _rb(wq, bf16)), bf16)              # mc:393
+    w = _rg(q @ k.transpose(-2, -1) * hs ** -0.5, bf16)    # mc:396 (scale after the matmul)
     tril = torch.tril(torch.ones(T, T))                    # mc:372-375, sliced [:T,:T] at :398
     w = w.masked_fill(tril == 0, float("-inf"))            # mc:397-399
     w = F.softmax(w, dim=-1)                               # mc:400
     if p > 0.0 or mask is not None:
         w = _drop(w, p, training, mask)                    # mc:401 (no renormalisation)
-    v = F.linear(x, wv)                                    # mc:404
-    return w @ v                                           # mc:405
+    v = _rb(F.linear(x, _rb(wv, bf16)), bf16)              # mc:404
+    return _rb(_rb(w, bf16) @ v, bf16)                     # mc:405
 
 
 def _num_heads(sd: SD, prefix: str) -> int:
@@ -85,17 +113,17 @@ def _num_heads(sd: SD, prefix: str) -> int:
 
 
 def mha_forward(sd: SD, prefix: str, x: Tensor, p: float = 0.0, training: bool = False,
-                masks: Optional[dict] = None) -> Tensor:
+                masks: Optional[dict] = None, bf16: bool = False) -> Tensor:
     """MultiHeadAttention / 2 / 3. ref: src/model_component.py:86-103 (cat only),
     :241-261 (+proj), :436-455 (+proj +dropout)."""
     nh = _num_heads(sd, prefix)
     outs = []
     for h in range(nh):
         m = None if masks is None else masks.get(f"{prefix}heads.{h}")
-        outs.append(head_forward(sd, f"{prefix}heads.{h}.", x, p, training, m))
+        outs.append(head_forward(sd, f"{prefix}heads.{h}.", x, p, training, m, bf16))
     out = torch.cat(outs, dim=-1)                          # mc:453
     if prefix + "proj.weight" in sd:
-        out = F.linear(out, sd[prefix + "proj.weight"], sd[prefix + "proj.bias"])   # mc:454
+        out = _rg(F.linear(out, _rb(sd[prefix + "proj.weight"], bf16), sd[prefix + "proj.bias"]), bf16)   # mc:454
         if p > 0.0 or masks is not None:
             m = None if masks is None else masks.get(f"{prefix}proj")
             out = _drop(out, p, training, m)
@@ -103,19 +131,19 @@ def mha_forward(sd: SD, prefix: str, x: Tensor, p: float = 0.0, training: bool =
 
 
 def ffn_forward(sd: SD, prefix: str, x: Tensor, p: float = 0.0, training: bool = False,
-                mask: Optional[Tensor] = None) -> Tensor:
+                mask: Optional[Tensor] = None, bf16: bool = False) -> Tensor:
     """FeedForward (Linear(C,C)+ReLU, mc:118-121), FeedForward2 (C->4C->C, mc:197-201),
     FeedForward3 (+Dropout, mc:320-325)."""
-    h = F.relu(F.linear(x, sd[prefix + "net.0.weight"], sd[prefix + "net.0.bias"]))
+    h = F.relu(F.linear(x, _rb(sd[prefix + "net.0.weight"], bf16), sd[prefix + "net.0.bias"]))
     if prefix + "net.2.weight" in sd:
-        h = F.linear(h, sd[prefix + "net.2.weight"], sd[prefix + "net.2.bias"])
+        h = _rg(F.linear(_rb(h, bf16), _rb(sd[prefix + "net.2.weight"], bf16), sd[prefix + "net.2.bias"]), bf16)
         if p > 0.0 or mask is not None:
             h = _drop(h, p, training, mask)
     return h
 
 
 def block_forward(sd: SD, prefix: str, kind: str, x: Tensor, p: float = 0.0,
-                  training: bool = False, masks: Optional[dict] = None) -> Tensor:
+                  training: bool = False, masks: Optional[dict] = None, bf16: bool = False) -> Tensor:
     """Block (mc:179-181), ResidualBlock (mc:303-305), ResidualBlock2 (mc:505-507)."""
     if kind == "Block":
         return ffn_forward(sd, prefix + "ffwd.", mha_forward(sd, prefix + "sa_head.", x))
@@ -124,11 +152,11 @@ def block_forward(sd: SD, prefix: str, kind: str, x: Tensor, p: float = 0.0,
         return x + ffn_forward(sd, prefix + "ffwd.", x)
     if kind == "ResidualBlock2":
         C = x.shape[-1]
-        h = F.layer_norm(x, (C,), sd[prefix + "ln1.weight"], sd[prefix + "ln1.bias"], 1e-5)
-        x = x + mha_forward(sd, prefix + "sa_head.", h, p, training, masks)
-        h = F.layer_norm(x, (C,), sd[prefix + "ln2.weight"], sd[prefix + "ln2.bias"], 1e-5)
+        h = _rb(F.layer_norm(x, (C,), sd[prefix + "ln1.weight"], sd[prefix + "ln1.bias"], 1e-5), bf16)
+        x = x + mha_forward(sd, prefix + "sa_head.", h, p, training, masks, bf16)
+        h = _rb(F.layer_norm(x, (C,), sd[prefix + "ln2.weight"], sd[prefix + "ln2.bias"], 1e-5), bf16)
         m = None if masks is None else masks.get(f"{prefix}ffwd")
-        return x + ffn_forward(sd, prefix + "ffwd.", h, p, training, m)
+        return x + ffn_forward(sd, prefix + "ffwd.", h, p, training, m, bf16)
     raise ValueError(kind)
 
 
@@ -146,9 +174,13 @@ def _num_layers(sd: SD) -> int:
 # the six LMs
 # --------------------------------------------------------------------------------------
 def lm_forward(model_name: str, sd: SD, idx: Tensor, targets: Optional[Tensor] = None,
-               p: float = 0.0, training: bool = False, masks: Optional[dict] = None
+               p: float = 0.0, training: bool = False, masks: Optional[dict] = None, bf16: bool = False
                ) -> Tuple[Tensor, Optional[Tensor]]:
     """forward(idx, targets) of any of the six LMs.
+
+    ``bf16=True`` (TransformerLM only) is NOT the reference's arithmetic: it inserts a bf16 rounding wherever the HIP
+    path's precision="bf16" mode stores an operand as bf16 (see _rb / _rg), so that the bf16 kernels can be held to a
+    tight per-tensor bound against "the reference computed with the same roundings" instead of a loose one against fp32.
 
     ref: BigramLM src/model.py:80-105; SingleHeadAttentionLM :176-203;
     MultiHeadAttentionLM :280-307; BlocksLM :381-408; ResidualBlocksLM :482-509;
@@ -168,13 +200,13 @@ def lm_forward(model_name: str, sd: SD, idx: Tensor, targets: Optional[Tensor] =
         else:
             kind = _BLOCK_KIND[model_name]
             for l in range(_num_layers(sd)):
-                x = block_forward(sd, f"blocks.{l}.", kind, x, p, training, masks)
-        logits = F.linear(x, sd["lm_head.weight"], sd["lm_head.bias"])                 # :599
+                x = block_forward(sd, f"blocks.{l}.", kind, x, p, training, masks, bf16)
+        logits = F.linear(_rb(x, bf16), _rb(sd["lm_head.weight"], bf16), sd["lm_head.bias"])   # :599
     if targets is None:
         return logits, None
     B, T, V = logits.shape
     logits = logits.view(B * T, V)                                                     # :605
-    loss = F.cross_entropy(logits, targets.view(B * T))                                # :606-607
+    loss = F.cross_entropy(_rg(logits, bf16), targets.view(B * T))                     # :606-607
     return logits, loss
 
 
@@ -284,6 +316,16 @@ def get_batch(data: Tensor, context_length: int, batch_size: int,
     return x, y
 
 
+def encode_corpus(text: str) -> Tuple[Tensor, Tensor, int, List[str]]:
+    """char tokenizer + 90/10 split: (train_data, val_data, vocab_size, vocab) as int64 streams -- the tensors
+    get_train_val_data saves to train_data.pt / val_data.pt (ref: src/preprocessing.py:3-26,68-79)."""
+    vocab = sorted(list(set(text)))                         # pp:14
+    stoi = {ch: i for i, ch in enumerate(vocab)}            # pp:19
+    data = torch.tensor([stoi[c] for c in text], dtype=torch.long)    # pp:20,69
+    n = len(data)
+    return data[:int(0.9 * n)], data[int(0.9 * n):], len(vocab), vocab   # pp:76-79
+
+
 def cyclic_lr(step_count: int, base_lr: float, max_lr: float, step_size_up: int = 5) -> float:
     """CyclicLR(mode='triangular', step_size_up=5, cycle_momentum=False) after
     ``step_count`` calls of scheduler.step(). ref: src/train.py:122-126,162."""
@@ -328,7 +370,7 @@ class AdamWState:
 
 
 def loss_and_grads(model_name: str, sd: SD, idx: Tensor, targets: Tensor, p: float = 0.0,
-                   training: bool = False, masks: Optional[dict] = None):
+                   training: bool = False, masks: Optional[dict] = None, bf16: bool = False):
     """logits, loss and d(loss)/d(param) for every trainable key (autograd over the
     restatement; ref: loss.backward() at src/train.py:150)."""
     keys = trainable_keys(model_name, sd)
@@ -338,7 +380,7 @@ def loss_and_grads(model_name: str, sd: SD, idx: Tensor, targets: Tensor, p: flo
         t = sd[k].detach().clone().requires_grad_(True)
         work[k] = t
         leaves.append(t)
-    logits, loss = lm_forward(model_name, work, idx, targets, p, training, masks)
+    logits, loss = lm_forward(model_name, work, idx, targets, p, training, masks, bf16)
     gs = torch.autograd.grad(loss, leaves, allow_unused=True)
     grads = {k: g for k, g in zip(keys, gs)}
     return logits.detach(), loss.detach(), grads

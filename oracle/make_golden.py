@@ -58,6 +58,27 @@ def ref_build(name, cfg, vocab=V):
     return getattr(ref_model, name)(**kw)
 
 
+def make_corpus_text(n_lines: int = 420, seed: int = 7) -> str:
+    """a small synthetic lyric-shaped text (own word list; no dataset is available offline): mixed case, digits, punctuation,
+    a few non-ASCII characters and blank lines, so that the char vocabulary is not trivially a-z"""
+    import random
+    rnd = random.Random(seed)
+    words = ("river stone lantern morning window ocean paper thunder quiet ember harbor signal velvet copper winter echo "
+             "meadow circuit marble feather garden mirror shadow anchor violet pepper candle bridge engine orchard "
+             "we you they never always again over under until because maybe slowly tonight tomorrow 7 24 1999").split()
+    tails = [",", ".", "", "!", "?", " --", ";", "...", " (yeah)", " é", " ñ"]
+    out = []
+    for i in range(n_lines):
+        n = rnd.randint(3, 9)
+        line = " ".join(rnd.choice(words) for _ in range(n))
+        line = line.capitalize() if rnd.random() < 0.8 else line.upper()
+        out.append(line + rnd.choice(tails))
+        if i % 17 == 16:
+            out.append("")
+            out.append(f"[Verse {i // 17 + 1}]")
+    return "\n".join(out) + "\n"
+
+
 def same(a, b, what):
     assert a.shape == b.shape, (what, a.shape, b.shape)
     assert torch.equal(a, b), f"oracle != reference for {what}: max|d|={(a - b).abs().max().item():.3e}"
@@ -230,6 +251,32 @@ def main():
     for i, lr in enumerate(seq):
         assert abs(R.cyclic_lr(i, R.TINY["base_lr"], R.TINY["max_lr"]) - lr) < 1e-15, (i, lr)
     summary["cyclic_lr"] = seq
+
+    # ---------------------------------------------------------------- data side: get_train_val_data (src/preprocessing.py:48-86)
+    import contextlib
+    import io
+    import tempfile
+    text_path = os.path.join(OUT, "corpus_fixture.txt")
+    if not os.path.exists(text_path):
+        with open(text_path, "w", encoding="utf-8") as f:
+            f.write(make_corpus_text())
+    with open(text_path, "r", encoding="utf-8") as f:
+        text = f.read()
+    with tempfile.TemporaryDirectory() as td:
+        tp, vp = os.path.join(td, "train_data.pt"), os.path.join(td, "val_data.pt")
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref_prep.get_train_val_data(text_path, tp, vp)           # the reference writes the two .pt files
+        rt = torch.load(tp, weights_only=True)
+        rv = torch.load(vp, weights_only=True)
+    ot, ov, ovocab, vocab = R.encode_corpus(text)
+    same(ot, rt, "train_data.pt")
+    same(ov, rv, "val_data.pt")
+    enc, dec, rvocab = ref_prep.get_mapper(text)
+    assert rvocab == ovocab and dec(rt[:200].tolist()) == text[:200] and enc(text[:50]) == ot[:50].tolist()
+    assert rt.dtype == torch.int64 and rt.dim() == 1
+    torch.save({"train": rt.to(torch.int16), "val": rv.to(torch.int16), "vocab_size": rvocab, "vocab": "".join(vocab)},
+               os.path.join(OUT, "corpus_fixture.pt"))
+    summary["corpus_fixture"] = {"chars": len(text), "vocab_size": rvocab, "n_train": len(rt), "n_val": len(rv)}
 
     with open(os.path.join(OUT, "summary.json"), "w") as f:
         json.dump(summary, f, indent=1)

@@ -208,3 +208,61 @@ def test_rccl_data_parallel_path_world_size_one():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_rccl_smoke.py")], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "RCCL data-parallel path ok" in r.stdout
+
+
+def test_out_of_range_ids_raise_like_torch(dev, golden_dir):
+    """nn.Embedding / F.cross_entropy raise on a bad id in the reference (ref: src/model.py:595,606); the kernels clamp (they must
+    never fault), so the Python layer raises where ids enter: module forward / generate, engine set_corpus / set_batch / host
+    offsets -- a vocabulary mismatch must not train on aliased ids with a plausible loss."""
+    import drakegpt_amd as D
+    m, eng, fix = _mk(dev, golden_dir)
+    x, y = fix["x"][0].clone(), fix["y"][0].clone()
+    bad = x.clone(); bad[3, 5] = V
+    neg = y.clone(); neg[0, 0] = -1
+    with pytest.raises(IndexError, match="out of range"):
+        m(bad.to(dev), y.to(dev))
+    with pytest.raises(IndexError, match="out of range"):
+        m(x.to(dev), neg.to(dev))
+    with pytest.raises(IndexError, match="out of range"):
+        m.eval().generate(bad[:1, :4].to(dev), 3)
+    with pytest.raises(IndexError, match="out of range"):
+        D.BigramLM(V).to(dev)(bad.to(dev))
+    with pytest.raises(IndexError, match="out of range"):
+        eng.set_batch(bad.to(dev), y.to(dev))
+    with pytest.raises(IndexError, match="out of range"):
+        eng.set_corpus(torch.arange(200) % (V + 1))
+    eng.set_corpus(torch.arange(200) % V)
+    with pytest.raises(IndexError, match="do not fit"):
+        eng.set_offsets(torch.full((32,), 200 - 8))           # needs T + 1 = 9 tokens from the offset on
+    eng.set_offsets(torch.full((32,), 200 - 9))
+    m.train()
+    logits, loss = m(x.to(dev), y.to(dev))                     # the valid batch still runs
+    assert torch.isfinite(loss)
+
+
+def test_train_harness_on_text_and_on_pt_files(dev, golden_dir, tmp_path, capsys):
+    """the data-side row: text -> get_train_val_data -> train_data.pt / val_data.pt -> train.py, and train.py on
+    the text directly; both see the same token streams, so with the same seed they print the same losses
+    (ref: src/preprocessing.py:48-86, src/train.py:94-100)."""
+    from drakegpt_amd import preprocessing, train
+    src = os.path.join(golden_dir, "corpus_fixture.txt")
+    tp, vp = str(tmp_path / "train_data.pt"), str(tmp_path / "val_data.pt")
+    _, _, vocab = preprocessing.get_train_val_data(src, tp, vp, verbose=False)
+    common = ["--model", "TransformerLM", "--iters", "8", "--eval-interval", "4", "--eval-iters", "3", "--precision", "fp32", "--no-save",
+              "--sample", "12"]
+    train.main(common + ["--data", src])
+    a = capsys.readouterr().out
+    train.main(common + ["--data", src, "--train-data", tp, "--val-data", vp])
+    b = capsys.readouterr().out
+    import json
+    la = [json.loads(l) for l in a.splitlines() if l.startswith("{")]
+    lb = [json.loads(l) for l in b.splitlines() if l.startswith("{")]
+    assert len(la) == 2 and [(r["train_loss"], r["val_loss"]) for r in la] == [(r["train_loss"], r["val_loss"]) for r in lb]
+    assert all(0 < r["val_loss"] < 6 for r in la) and la[1]["lr"] == pytest.approx(2.6e-3)
+    # the sample is decoded with the text's own mapper: characters of the fixture's vocabulary
+    fix = torch.load(os.path.join(golden_dir, "corpus_fixture.pt"), weights_only=True)
+    sample = a[a.rindex("}\n") + 2:]                        # everything after the last JSON line: 1 start token + 12 sampled + newline
+    assert len(sample) == 14 and set(sample) <= set(fix["vocab"]) | {"\n"} and vocab == fix["vocab_size"]
+    # .pt files alone (no text): the vocabulary is taken from the streams
+    train.main(common + ["--train-data", tp, "--val-data", vp, "--iters", "4"])
+    assert '"val_loss"' in capsys.readouterr().out

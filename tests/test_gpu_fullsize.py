@@ -69,6 +69,11 @@ def test_odd_vocab_and_ragged_T_engine_vs_module(dev, precision):
     views = dict(wq=eng.grad_view("0.wqkv"), w1=eng.grad_view("1.w1"), lm=eng.grad_view("lm.w"), lmb=eng.grad_view("lm.b"),
                  tok=eng.grad_view("tok"), pos=eng.grad_view("pos"), ln=eng.grad_view("0.ln1w"))
     H = C // NH
+    if __import__("os").environ.get("DG_TEST_REPORT"):
+        print(f"[parity] odd-vocab engine vs module {precision}: " + ", ".join(f"{k}={rel(v, r):.2e}" for k, v, r in (
+            ("wq", views["wq"][:H], ref["blocks.0.sa_head.heads.0.query.weight"]), ("w1", views["w1"], ref["blocks.1.ffwd.net.0.weight"]),
+            ("lm", views["lm"], ref["lm_head.weight"]), ("lmb", views["lmb"], ref["lm_head.bias"]), ("tok", views["tok"], ref["token_embedding_table.weight"]),
+            ("pos", views["pos"], ref["position_embedding_table.weight"]), ("ln", views["ln"], ref["blocks.0.ln1.weight"]))), flush=True)
     assert rel(views["wq"][:H], ref["blocks.0.sa_head.heads.0.query.weight"]) < 20 * tol
     assert rel(views["w1"], ref["blocks.1.ffwd.net.0.weight"]) < 20 * tol
     assert rel(views["lm"], ref["lm_head.weight"]) < 20 * tol and rel(views["lmb"], ref["lm_head.bias"]) < 20 * tol
@@ -129,3 +134,61 @@ def test_gemm_linearity_and_ce_gradient_identity_full_size(dev):
     dl = torch.empty(512, 50264, device=dev)
     rows = ops.cross_entropy(logits, tgt, V, dlogits=dl, grad_scale=1.0)
     assert rows.min().item() >= 0 and dl[:, :V].sum(1).abs().max().item() < 1e-4
+
+
+def test_gpt2_small_shape_engine_steps(dev):
+    """BASELINE.json configs[2]: GPT-2-small shape (V 50257, C 768, T 1024, 12 heads, 12 layers), bf16, B = 2.  Two captured
+    engine steps: loss finite and near ln V at init, falling after one AdamW step on the same batch; the engine's gradient equals
+    the autograd (module) path's on the same (seed, step) dropout masks; size-independent properties of the gradient.
+    (The oracle at this size needs ~20 s / step on the host and 40 GB of autograd state: the engine is tied to the oracle at
+    the scaled configuration in test_gpu_engine_oracle.py and to the module path here.)  ref: src/model.py:558-609."""
+    import math
+    import drakegpt_amd as D
+    from drakegpt_amd.config import GPT2_SMALL as cfg
+    from drakegpt_amd.engine import TrainEngine
+    V, C, T, NH, L, p, B = cfg["vocab_size"], cfg["embedding_dim"], cfg["context_length"], cfg["num_heads"], cfg["num_layers"], cfg["dropout"], 2
+    torch.manual_seed(42)
+    m = D.TransformerLM(V, C, T, NH, L, p, precision="bf16").to(dev).train()
+    assert sum(q.numel() for q in m.parameters()) == 163059793            # SURVEY 8a
+    g = torch.Generator().manual_seed(11)
+    x = torch.randint(0, V, (B, T), generator=g).to(dev)
+    y = torch.randint(0, V, (B, T), generator=g).to(dev)
+    seed = 31337
+    m.seed_dropout(seed)
+    logits, loss = m(x, y)
+    assert logits.shape == (B * T, V)
+    loss.backward()
+    ref = {k: q.grad.detach().clone() for k, q in m.named_parameters() if q.grad is not None}
+    l_mod = loss.item()
+    del logits, loss
+    m.zero_grad(set_to_none=True)
+    torch.cuda.empty_cache()
+    eng = TrainEngine(m, B, T, lr=cfg["base_lr"], betas=cfg["betas"], seed=seed, use_graph=True)
+    assert eng.grouped_dw and eng.onehot is None          # V = 50257: the token-table gradient keeps the atomic scatter-add
+    eng.set_batch(x, y)
+    l0 = eng.step().item()
+    torch.cuda.synchronize()
+    assert math.isfinite(l0) and abs(l0 - l_mod) < 5e-3 * l_mod
+    assert math.log(V) - 0.5 < l0 < math.log(V) + 3.0, l0
+    grads = eng.named_grads()
+    assert set(grads) == set(ref)
+    flat = torch.cat([grads[k].reshape(-1).double() for k in ref])
+    flat_ref = torch.cat([ref[k].reshape(-1).double() for k in ref])
+    e_flat = ((flat - flat_ref).norm() / flat_ref.norm()).item()
+    worst = max(((k, rel(grads[k], ref[k])) for k in ref), key=lambda kv: kv[1])
+    if __import__("os").environ.get("DG_TEST_REPORT"):
+        print(f"[parity] gpt2-small engine vs module: flat {e_flat:.3e}, worst tensor {worst}", flush=True)
+    assert e_flat < 1.5e-2 and worst[1] < 5e-2, (e_flat, worst)
+    # properties: softmax-minus-one-hot rows sum to zero => so does the lm_head bias gradient; token rows that do not occur in the
+    # batch get exactly zero; position rows are all used (T = context length)
+    gb = grads["lm_head.bias"].double()
+    assert abs(gb.sum().item()) < 1e-3 * gb.abs().sum().item()
+    gt = grads["token_embedding_table.weight"]
+    unseen = torch.ones(V, dtype=torch.bool, device=dev)
+    unseen[x.reshape(-1)] = False
+    assert torch.all(gt[unseen] == 0) and torch.all(gt[~unseen].abs().sum(1) > 0)
+    assert torch.all(grads["position_embedding_table.weight"].abs().sum(1) > 0)
+    assert torch.equal(m.ln_f.weight, torch.ones_like(m.ln_f.weight))
+    l1 = eng.step().item()                                 # same batch again, after one AdamW step: a graph replay
+    assert math.isfinite(l1) and l1 < l0, (l0, l1)
+    assert eng.step_count() == 2

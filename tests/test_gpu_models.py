@@ -113,10 +113,20 @@ def test_train_mode_dropout_matches_oracle_with_same_masks(dev, golden_dir, prec
         flat = torch.cat([dict(m.named_parameters())[k].grad.reshape(-1).cpu() for k in names])
         flat_ref = torch.cat([grads[k].reshape(-1) for k in names])
         assert rel(flat, flat_ref) < 2 * tol, (step, rel(flat, flat_ref))
-        for k, p in m.named_parameters():
-            if p.grad is not None:
-                # per tensor: small q/k gradients carry more bf16 round-off than the whole vector
-                assert rel(p.grad, grads[k]) < (3e-4 if precision == "fp32" else 0.3), (step, k, rel(p.grad, grads[k]))
+        if precision == "fp32":
+            for k, p in m.named_parameters():
+                if p.grad is not None:
+                    assert rel(p.grad, grads[k]) < 3e-4, (step, k, rel(p.grad, grads[k]))
+        else:
+            # per tensor the bf16 path is held against the reference computed WITH the kernels' bf16 roundings (oracle
+            # bf16=True): small q/k gradients carry 10 %+ of bf16 round-off relative to fp32, which a bound against the fp32
+            # arithmetic could only cover by being loose enough to pass a wrong term
+            lo2, ls2, g2 = R.loss_and_grads("TransformerLM", sd, x, y, p=0.1, training=True, masks=masks, bf16=True)
+            per = {k: rel(p.grad, g2[k]) for k, p in m.named_parameters() if p.grad is not None}
+            worst = max(per.items(), key=lambda kv: kv[1])
+            if os.environ.get("DG_TEST_REPORT"):
+                print(f"[parity] tiny bf16 module vs bf16-rounded oracle step {step}: logits {rel(logits, lo2):.3e} worst {worst}", flush=True)
+            assert rel(logits, lo2) < 1e-2 and worst[1] < 6e-2, (step, rel(logits, lo2), sorted(per.items(), key=lambda kv: -kv[1])[:6])
 
 
 def test_bf16_logits_close(dev, golden_dir):

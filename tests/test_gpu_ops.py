@@ -186,6 +186,37 @@ def test_gemm_tn_grouped(dev, with_short):
                               torch.zeros(64 * 64, device=dev), 64, 64)])
 
 
+def _tn_status(ws):
+    return int(ws[-16:].view(torch.int32)[0].item())
+
+
+@pytest.mark.parametrize("R", [128, 704])
+def test_gemm_tn_grouped_every_tile_split_single_round(dev, R):
+    """one layer's problem set (66 tiles): every tile is cut into two K halves, ONE item per workgroup (144 <= #CUs), the second
+    half on workgroup 72 + t waiting for workgroup t.  Same result as the unsplit launch; the bounded wait never runs out."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R)
+    C, V = 384, 80
+    shapes = [(C, 4 * C), (4 * C, C), (C, C), (3 * C, C), (V, C)]
+    assert sum(((P + 255) // 256) * ((Q + 127) // 128) for P, Q in shapes) == 66
+    probs, outs = [], []
+    for P, Q in shapes:
+        A = torch.randn(R, (P + 7) // 8 * 8, generator=g).to(torch.bfloat16).to(dev)
+        B = torch.randn(R, Q, generator=g).to(torch.bfloat16).to(dev)
+        outs.append(torch.full((P * Q,), float("nan"), device=dev))
+        probs.append((A[:, :P], B, outs[-1], P, Q))
+    ws = ops.gemm_tn_grouped_workspace(probs, dev)
+    ops.gemm_tn_grouped(probs, None)
+    whole = [o.clone() for o in outs]
+    for _ in range(2):
+        for o in outs:
+            o.fill_(float("nan"))
+        ops.gemm_tn_grouped(probs, ws)
+        for (A, B, _, P, Q), o, w in zip(probs, outs, whole):
+            assert rel(o.view(P, Q), A.double().T @ B.double()) < 3e-6 and rel(o, w) < 1e-6
+    assert _tn_status(ws) == 0
+
+
 @pytest.mark.parametrize("R", [192, 1024])
 def test_gemm_tn_grouped_leftover_split(dev, R):
     """the training step's own problem set (6 layers x 4 Linears + lm_head + token table = 384 tiles of 256 x 128): with the
@@ -217,6 +248,41 @@ def test_gemm_tn_grouped_leftover_split(dev, R):
     for a, b, w, (P, Q) in zip(runs[0], runs[1], whole, shapes):
         assert torch.equal(a, b)
         assert rel(a, w) < 1e-6, (P, Q)
+    assert _tn_status(ws) == 0
+
+
+def test_gemm_tn_grouped_leftover_switch_off_never_splits_multi_round(dev):
+    """DG_TN_LEFTOVER=0 (A/B switch, read once per process: child process): with 384 tiles on 256 CUs "cut every tile" would put
+    second halves on lower-numbered workgroups than their producers (a deadlock when part of the grid is not resident -- ADVICE
+    r1); the launch rules now refuse that and run whole tiles: correct results, error word clear."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, torch
+sys.path.insert(0, %r)
+from drakegpt_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(3)
+C, V, R = 384, 80, 256
+shapes = [(V, C)] + [(C, 4 * C), (4 * C, C), (C, C), (3 * C, C)] * 6 + [(V, C)]
+probs = []
+for P, Q in shapes:
+    A = torch.randn(R, (P + 7) // 8 * 8, generator=g).to(torch.bfloat16).to(dev)
+    B = torch.randn(R, Q, generator=g).to(torch.bfloat16).to(dev)
+    probs.append((A[:, :P], B, torch.full((P * Q,), float("nan"), device=dev), P, Q))
+ws = ops.gemm_tn_grouped_workspace(probs, dev)
+ops.gemm_tn_grouped(probs, ws)
+torch.cuda.synchronize()
+for A, B, o, P, Q in probs:
+    ref = A.double().T @ B.double()
+    assert ((o.view(P, Q).double() - ref).norm() / ref.norm()).item() < 3e-6
+assert int(ws[-16:].view(torch.int32)[0].item()) == 0
+print("leftover-off ok")
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DG_TN_LEFTOVER="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "leftover-off ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
 @pytest.mark.parametrize("G,n,stride", [(256, 23104, 23104), (256, 1000, 1024), (37, 4096, 4100), (32, 2050, 2052), (8, 77, 80), (300, 64, 64)])
@@ -288,6 +354,64 @@ def test_layernorm(dev, C, out_dtype):
     else:
         with pytest.raises(RuntimeError):
             ops.layernorm_bwd(dy.bfloat16().to(dev), x.to(dev), w.to(dev), mean, rstd, dres.to(dev), pg, pb, C, G)
+
+
+@pytest.mark.parametrize("C", [32, 384, 768, 1024])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+@pytest.mark.parametrize("dy_dtype,g_dtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16)])
+def test_layernorm_bwd_fused(dev, C, p, dy_dtype, g_dtype):
+    """dg_layernorm_bwd_fused against fp64: dx = dresid + LN'(dy) (ref: nn.LayerNorm at src/model_component.py:488-489 under the
+    residual add of :505-506), g = dropout_bwd(dx) with the keep-mask of `site` (ref: backward of nn.Dropout at :454 / :324, mask
+    from oracle/rng_ref.py), the bias partial rows = column sums of the unrounded g, and the dgamma / dbeta partials."""
+    from oracle import rng_ref
+    ops = _ops()
+    M, G, site, seed, step = 1000, 24, 9, 4321, 3           # ragged row chunks: 1000 = 23 * 42 + 34
+    gen = torch.Generator().manual_seed(C + int(100 * p))
+    x = torch.randn(M, C, generator=gen) * 1.5 - 0.3
+    w = torch.randn(C, generator=gen)
+    b = torch.randn(C, generator=gen)
+    dy = torch.randn(M, C, generator=gen).to(dy_dtype)
+    dres = torch.randn(M, C, generator=gen)
+    xd = x.double().requires_grad_(True)
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xd, (C,), wd, bd, 1e-5).backward(dy.double())
+    dx_ref = xd.grad + dres.double()
+    keep = torch.from_numpy(rng_ref.keep_mask(seed, step, site, p, M * C).reshape(M, C)).double() if p > 0 else torch.ones(M, C).double()
+    g_ref = dx_ref * keep / (1.0 - p)
+    _, mean, rstd = ops.layernorm_fwd(x.to(dev), w.to(dev), b.to(dev), torch.float32)
+    pg, pb, pq = (torch.full((G, C + 8), float("nan"), device=dev) for _ in range(3))
+    rng = ops.new_rng_state(seed, dev, step)
+    dx, gq = ops.layernorm_bwd_fused(dy.to(dev), x.to(dev), w.to(dev), mean, rstd, dres.to(dev), pg, pb, C + 8, G, g_dtype, p, rng, site, pq)
+    torch.cuda.synchronize()
+    assert gq.dtype == g_dtype and gq.shape == (M, C)
+    assert rel(dx, dx_ref) < 2e-6
+    if g_dtype == torch.float32:
+        assert rel(gq, g_ref) < 2e-6
+    else:
+        # exactly the bf16 rounding of the kernel's own fp32 g: dropped elements are exact zeros, kept ones within half an ulp
+        assert torch.all(gq.float().cpu()[keep == 0] == 0)
+        assert rel(gq, g_ref) < 3e-3 and maxabs(gq, g_ref.float().bfloat16()) <= 2 ** -7 * g_ref.abs().max().item()
+    out = torch.empty(3, C, device=dev)
+    for i, part in enumerate((pg, pb, pq)):
+        assert torch.isfinite(part[:, :C]).all()            # every partial row written
+        ops.reduce_partials(part, C + 8, G, out[i], C)
+    assert rel(out[0], wd.grad) < 3e-6 and rel(out[1], bd.grad) < 3e-6
+    assert rel(out[2], g_ref.sum(0)) < 3e-6                 # column sums of g BEFORE the bf16 rounding
+    # without a bias behind it (first block: g is the X operand of the token-table problem): gbias_part = NULL
+    dx2, g2 = ops.layernorm_bwd_fused(dy.to(dev), x.to(dev), w.to(dev), mean, rstd, None, pg, pb, C + 8, G, g_dtype, 0.0, None, 0, None)
+    assert rel(dx2, xd.grad) < 2e-6 and rel(g2, xd.grad) < (2e-6 if g_dtype == torch.float32 else 3e-3)
+
+
+def test_layernorm_bwd_fused_rejects_unsupported_width(dev):
+    ops = _ops()
+    M, C = 64, 1028 * 2
+    assert not ops.layernorm_bwd_fused_supported(C) and not ops.layernorm_bwd_fused_supported(30)
+    z = torch.zeros(M, C, device=dev)
+    v = torch.zeros(C, device=dev)
+    r = torch.zeros(M, device=dev)
+    part = torch.zeros(4, C, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.layernorm_bwd_fused(z, z, v, r, r, None, part, part, C, 4, torch.float32, 0.0, None, 0, None)
 
 
 def _attn_ref(qkv, B, T, NH, H, keep=None, p=0.0):

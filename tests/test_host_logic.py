@@ -127,3 +127,89 @@ def test_dropout_hash_reference_properties():
         assert abs(np.corrcoef(k[:-lag], k[lag:])[0, 1]) < 4e-3, lag
     rows = k.reshape(-1, 256).sum(1)
     assert 0.93 < rows.var() / (256 * 0.2 * 0.8) < 1.07
+
+
+# ------------------------------------------------------------------------------------------------ data side
+def test_get_train_val_data_writes_the_reference_files(golden_dir, tmp_path, capsys):
+    """tests/golden/corpus_fixture.pt holds what the REFERENCE's get_train_val_data wrote for corpus_fixture.txt
+    (oracle/make_golden.py ran it, ref: src/preprocessing.py:48-86): same tokens, same split, int64, bare tensors."""
+    fix = torch.load(os.path.join(golden_dir, "corpus_fixture.pt"), weights_only=True)
+    src = os.path.join(golden_dir, "corpus_fixture.txt")
+    tp, vp = str(tmp_path / "train_data.pt"), str(tmp_path / "val_data.pt")
+    tr, va, vocab = preprocessing.get_train_val_data(src, tp, vp)
+    out = capsys.readouterr().out
+    assert f"Vocab size of the text: {fix['vocab_size']}" in out and "Input (decoded):" in out
+    lt, lv = preprocessing.load_train_val_data(tp, vp)
+    for got, mem, want in ((lt, tr, fix["train"]), (lv, va, fix["val"])):
+        assert got.dtype == torch.int64 and got.dim() == 1
+        assert torch.equal(got, want.to(torch.int64)) and torch.equal(mem, got)
+    assert vocab == fix["vocab_size"] == len(fix["vocab"])
+    # a saved split is a tensor of its own, not a view dragging the whole corpus along
+    assert os.path.getsize(vp) < 8 * len(lv) + 4096
+    # the oracle's restatement agrees, and the mapper round-trips the text
+    text = open(src, encoding="utf-8").read()
+    ot, ov, ovocab, chars = R.encode_corpus(text)
+    assert torch.equal(ot, lt) and torch.equal(ov, lv) and ovocab == vocab and "".join(chars) == fix["vocab"]
+    enc, dec, _ = preprocessing.get_mapper(text)
+    assert dec(lt[:300].tolist()) == text[:300] and enc(text[-40:]) == lv[-40:].tolist()
+
+
+def test_load_train_val_data_rejects_other_formats(tmp_path):
+    good, bad = str(tmp_path / "a.pt"), str(tmp_path / "b.pt")
+    torch.save(torch.arange(10), good)
+    torch.save(torch.arange(10, dtype=torch.int32), bad)
+    with pytest.raises(ValueError, match="int64"):
+        preprocessing.load_train_val_data(good, bad)
+    torch.save({"data": torch.arange(10)}, bad)
+    with pytest.raises(ValueError, match="1-D int64"):
+        preprocessing.load_train_val_data(bad, good)
+
+
+@pytest.mark.parametrize("iters,interval,world", [(10, 5, 1), (13, 5, 1), (7, 3, 2), (4, 10, 1)])
+def test_staged_offsets_equal_the_reference_draw_order(iters, interval, world):
+    """engine_loop stages the window offsets of a whole evaluation interval at once; the draws must be the ones the
+    reference's per-step loop makes, with evaluate_loss's draws from the same global generator in between
+    (ref: src/train.py:141-172, src/preprocessing.py:43), also when iters is not a multiple of the interval."""
+    n_train, T, B, eval_iters = 5000, 8, 4, 3
+
+    class FakeEngine:
+        def __init__(self, rank):
+            self.rank, self.seen = rank, []
+
+        def check_offsets(self, ix):
+            assert ix.min() >= 0 and ix.max() + T + 1 <= n_train
+
+        def set_offsets(self, ix):
+            self.seen.append(ix.clone())
+
+        def step(self):
+            pass
+
+    def eval_draws(gen, sink):
+        for _ in range(2 * eval_iters):                               # train, then val: evaluate_loss's draws
+            sink.append(preprocessing.draw_offsets(n_train, T, B, gen))
+
+    for rank in range(world):
+        gen = torch.Generator().manual_seed(42)
+        eng, ev = FakeEngine(rank), []
+        train.engine_loop(eng, n_train, T, B, rank, world, iters, interval, lambda it: eval_draws(gen, ev), "cpu", generator=gen)
+        # the reference order, one draw per step
+        gen2 = torch.Generator().manual_seed(42)
+        want, ev2 = [], []
+        for it in range(iters):
+            ix = torch.randint(n_train - T, (B * world,), generator=gen2)
+            want.append(ix[rank * B:(rank + 1) * B])
+            if (it + 1) % interval == 0:
+                eval_draws(gen2, ev2)
+        assert len(eng.seen) == iters and all(torch.equal(a, b) for a, b in zip(eng.seen, want))
+        assert len(ev) == len(ev2) and all(torch.equal(a, b) for a, b in zip(ev, ev2))
+        assert torch.equal(torch.randint(100, (4,), generator=gen), torch.randint(100, (4,), generator=gen2))
+
+
+def test_check_ids_raises_like_torch():
+    from drakegpt_amd import ops
+    ops.check_ids(torch.tensor([[0, 79]]), 80, "idx")
+    for bad in ([[0, 80]], [[-1, 3]]):
+        with pytest.raises(IndexError, match="out of range"):
+            ops.check_ids(torch.tensor(bad), 80, "idx")
+    ops.check_ids(torch.zeros((0,), dtype=torch.long), 80, "idx")
