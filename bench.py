@@ -334,18 +334,30 @@ def kernel_roofline(eng, offsets, peak_tflops):
             setattr(ops, n_, f_)
     snap = (eng.flat.clone(), eng.m_.clone(), eng.v_.clone())       # the AdamW replays below must not train the model away
     hagg = {}
+    side = torch.cuda.Stream()
     for sym, nb, fn in hbm:
-        fn(); fn()
+        # ten launches inside one captured graph: these kernels take 8-50 us, less than an eager ctypes launch + allocation
+        # costs on the host, and inside the training step they run from a graph too
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn(); fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(10):
+                fn()
+        gr.replay()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        for _ in range(10):
-            fn()
+        gr.replay()
         e.record()
         e.synchronize()
         a = hagg.setdefault(sym, [0.0, 0.0, 0])
         a[0] += nb
         a[1] += s.elapsed_time(e) * 1e-3 / 10
         a[2] += 1
+        del gr
     eng.flat.copy_(snap[0]); eng.m_.copy_(snap[1]); eng.v_.copy_(snap[2])
     eng.refresh_shadows()
     hbm_kernels = {k: {"achieved_GBs": v[0] / v[1] / 1e9, "frac_of_8TBs": v[0] / v[1] / 1e9 / PEAK_HBM_GBS, "avg_us": 1e6 * v[1] / v[2],

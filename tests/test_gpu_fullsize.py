@@ -64,8 +64,11 @@ def test_odd_vocab_and_ragged_T_engine_vs_module(dev, precision):
     eng = TrainEngine(m, B, T, lr=0.0, weight_decay=0.0, use_graph=False)
     eng.set_batch(x, y)
     l2 = eng.step()
-    tol = 1e-5 if precision == "fp32" else 2e-2
-    assert abs(l2.item() - loss.item()) < max(tol, 1e-5) * abs(loss.item())
+    # measured (round 2): the two paths run the same kernels on the same operands -- every tensor bit-identical except the
+    # atomically accumulated token table (1e-8) and, in bf16, lm_head.bias (1.6e-3: the engine's cross entropy hands dlogits
+    # over in bf16 and the bias gradient is their column sum; the module path sums the fp32 dlogits)
+    tol = 1e-6 if precision == "fp32" else 4e-3
+    assert abs(l2.item() - loss.item()) < 1e-5 * abs(loss.item())
     views = dict(wq=eng.grad_view("0.wqkv"), w1=eng.grad_view("1.w1"), lm=eng.grad_view("lm.w"), lmb=eng.grad_view("lm.b"),
                  tok=eng.grad_view("tok"), pos=eng.grad_view("pos"), ln=eng.grad_view("0.ln1w"))
     H = C // NH
@@ -74,12 +77,12 @@ def test_odd_vocab_and_ragged_T_engine_vs_module(dev, precision):
             ("wq", views["wq"][:H], ref["blocks.0.sa_head.heads.0.query.weight"]), ("w1", views["w1"], ref["blocks.1.ffwd.net.0.weight"]),
             ("lm", views["lm"], ref["lm_head.weight"]), ("lmb", views["lmb"], ref["lm_head.bias"]), ("tok", views["tok"], ref["token_embedding_table.weight"]),
             ("pos", views["pos"], ref["position_embedding_table.weight"]), ("ln", views["ln"], ref["blocks.0.ln1.weight"]))), flush=True)
-    assert rel(views["wq"][:H], ref["blocks.0.sa_head.heads.0.query.weight"]) < 20 * tol
-    assert rel(views["w1"], ref["blocks.1.ffwd.net.0.weight"]) < 20 * tol
-    assert rel(views["lm"], ref["lm_head.weight"]) < 20 * tol and rel(views["lmb"], ref["lm_head.bias"]) < 20 * tol
-    assert rel(views["tok"], ref["token_embedding_table.weight"]) < 20 * tol
-    assert rel(views["pos"], ref["position_embedding_table.weight"]) < 20 * tol and torch.all(views["pos"][T:] == 0)
-    assert rel(views["ln"], ref["blocks.0.ln1.weight"]) < 20 * tol
+    assert rel(views["wq"][:H], ref["blocks.0.sa_head.heads.0.query.weight"]) < tol
+    assert rel(views["w1"], ref["blocks.1.ffwd.net.0.weight"]) < tol
+    assert rel(views["lm"], ref["lm_head.weight"]) < tol and rel(views["lmb"], ref["lm_head.bias"]) < tol
+    assert rel(views["tok"], ref["token_embedding_table.weight"]) < tol
+    assert rel(views["pos"], ref["position_embedding_table.weight"]) < tol and torch.all(views["pos"][T:] == 0)
+    assert rel(views["ln"], ref["blocks.0.ln1.weight"]) < tol
 
 
 def test_attention_causality_and_dropout_determinism_T1024(dev):
@@ -178,7 +181,7 @@ def test_gpt2_small_shape_engine_steps(dev):
     worst = max(((k, rel(grads[k], ref[k])) for k in ref), key=lambda kv: kv[1])
     if __import__("os").environ.get("DG_TEST_REPORT"):
         print(f"[parity] gpt2-small engine vs module: flat {e_flat:.3e}, worst tensor {worst}", flush=True)
-    assert e_flat < 1.5e-2 and worst[1] < 5e-2, (e_flat, worst)
+    assert e_flat < 1e-5 and worst[1] < 5e-4, (e_flat, worst)        # measured 4.2e-7 / 3.3e-5 (lm_head.bias, as above)
     # properties: softmax-minus-one-hot rows sum to zero => so does the lm_head bias gradient; token rows that do not occur in the
     # batch get exactly zero; position rows are all used (T = context length)
     gb = grads["lm_head.bias"].double()
