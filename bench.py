@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs leg (p = 0, B = 256, GPT-2-small)")
     ap.add_argument("--dropout", type=float, default=None, help="override the preset's dropout")
+    ap.add_argument("--dp-buckets", type=int, default=None, help="N > 1: layer groups whose gradient ranges are all-reduced while the "
+                    "next group's backward runs (default: by gradient size, see TrainEngine._choose_buckets)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,7 +106,8 @@ def main():
                             precision=args.precision).to(dev)
     n_params = sum(p.numel() for p in model.parameters())
     eng = TrainEngine(model, B, T, lr=cfg["base_lr"], betas=cfg["betas"], seed=42, rank=rank, world_size=world,
-                      process_group=pg, use_graph=not args.no_graph)
+                      process_group=pg, use_graph=not args.no_graph, dp_buckets=args.dp_buckets)
+    dp_buckets = eng.dp_buckets
     n_corpus = 1_000_000 if V <= 256 else 10_000_000
     corpus = torch.randint(0, V, (n_corpus,), generator=torch.Generator().manual_seed(42))
     eng.set_corpus(corpus)
@@ -180,7 +183,7 @@ def main():
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"TransformerLM_{args.config}: V={V} C={cfg['embedding_dim']} T={T} heads={cfg['num_heads']} "
                                    f"layers={cfg['num_layers']} dropout={cfg['dropout']}; fwd+bwd+AdamW; hipGraph={'off' if args.no_graph else 'on'}",
-                       "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
+                       "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}", "dp_gradient_buckets": dp_buckets,
                        "params": n_params},
             "model_flops_per_token": fpt,
             "achieved_tflops_per_gpu": tok_s * fpt / 1e12 / world,

@@ -71,23 +71,41 @@ class FlatSink:
     def __init__(self, eng: "TrainEngine"):
         self.e = eng
         self.deferred = []           # (dY, X, dW view, P, Q): operands stay referenced until the grouped launch
+        self.small_pending = []      # (slabs, n, splits, out): split-K partials of the small problems, reduced at the next flush
 
     def defer(self, key, dy, x, P, Q) -> bool:
         if not self.e.grouped_dw:
             return False
+        if key in self.e.small_dw:
+            return False                              # bucketed data-parallel step, tiny problem: own split-K launch (matrix())
         off, shape = self.e._region(key)              # GEMM weights, or the token table (one-hot dY)
         assert shape == (P, Q), (key, shape, P, Q)
         self.deferred.append((dy, x, self.e.gflat[off:off + P * Q], P, Q))
         return True
 
-    def flush(self):
+    def flush(self, group: int = 0):
+        """one grouped launch for everything deferred so far (the whole backward pass, or one layer group of a bucketed
+        data-parallel step: every group has its own problem set, hence its own workspace)"""
         if self.deferred:
-            if self.e.tn_workspace is None:            # first step: sized for this problem set, zero-filled once
-                self.e.tn_workspace = ops.gemm_tn_grouped_workspace(self.deferred, self.e.dev)
-            ops.gemm_tn_grouped(self.deferred, self.e.tn_workspace)
+            ws = self.e.tn_workspaces.get(group)
+            if ws is None:                             # first step: sized for this problem set, zero-filled once
+                ws = self.e.tn_workspaces[group] = ops.gemm_tn_grouped_workspace(self.deferred, self.e.dev)
+            ops.gemm_tn_grouped(self.deferred, ws)
             self.deferred = []
+        for slab, n, splits, out in self.small_pending:
+            ops.reduce_partials(slab, n, splits, out, n)
+        self.small_pending = []
 
     def matrix(self, key, P, Q):
+        if key in self.e.small_dw:
+            # a few-tile problem (lm_head / token table at a char-level vocabulary) inside a bucketed step: as one more problem
+            # of a 126-tile group it would push the grouped launch past one round of half tiles, so it gets its own split-K
+            # launch into a small slab buffer, summed into the flat gradient right away (deterministic order)
+            slab, n = self.e.small_dw[key]
+            goff, shape = self.e._region(key)
+            assert shape == (P, Q), (key, shape, P, Q)
+            self.small_pending.append((slab, P * Q, n, self.e.gflat[goff:goff + P * Q]))
+            return slab, P * Q, n
         off, shape = self.e.layA.entries[key]
         assert shape == (P, Q), (key, shape, P, Q)
         # slabs beyond this matrix's own split count are never written: they stay zero from allocation
@@ -114,7 +132,8 @@ class FlatSink:
 class TrainEngine:
     def __init__(self, model: TransformerLM, batch_size: int, context_length: Optional[int] = None, *,
                  lr: float = 1e-3, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 seed: int = 42, rank: int = 0, world_size: int = 1, process_group=None, use_graph: bool = True):
+                 seed: int = 42, rank: int = 0, world_size: int = 1, process_group=None, use_graph: bool = True,
+                 dp_buckets: Optional[int] = None):
         if not isinstance(model, TransformerLM):
             raise TypeError("TrainEngine drives TransformerLM (the other five models train through the autograd path)")
         p0 = next(model.parameters())
@@ -136,6 +155,7 @@ class TrainEngine:
         self.M = self.B * self.T
         self.rank, self.world, self.pg = rank, world_size, process_group
         self.use_graph = use_graph
+        self._dp_buckets_arg = dp_buckets
         g = S.granule(self.act)
         if self.C % g or (self.NH * self.H) % g:
             raise ValueError(f"embedding_dim must be a multiple of {g} for {self.act}")
@@ -145,6 +165,7 @@ class TrainEngine:
         # flat gradient (no split-K slabs); fp32 parity mode keeps the per-matrix split-K path
         self.grouped_dw = self.act == torch.bfloat16 and self.M % 64 == 0
         self._build_layout()
+        self.dp_buckets = self._choose_buckets(self._dp_buckets_arg)
         self._alloc_and_adopt()
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay], dtype=torch.float32, device=self.dev)
         # dropout stream differs per data-parallel rank; the step word also drives Adam's bias correction
@@ -159,6 +180,8 @@ class TrainEngine:
         import os
         self.last_block_act = os.environ.get("DG_LAST_BLOCK_ACT", "1") != "0"      # 0: fp32 output + cast launch (A/B runs)
         self.force_dp_path = False      # rehearsal hook (tools/dp_rccl_smoke.py): take the multi-rank path with one rank
+        self.debug_timing = False       # multi-rank step only: HIP events around backward graph(s) / exchange / optimizer graph -> last_timing (ms)
+        self.last_timing: Optional[dict] = None
         self.keep_logits = False        # parity tests: keep the step's logits [M, V] alive as `last_logits` (also inside a captured graph)
         self.last_logits: Optional[Tensor] = None
         self.refresh_shadows()
@@ -187,6 +210,43 @@ class TrainEngine:
         self.n_active = self.offE + E.size           # optimizer / all-reduce range
         self.offZ = self.n_active
         self.n_total = self.n_active + Z.size
+
+    # -------------------------------------------------------------------------------- data-parallel plan
+    def _choose_buckets(self, arg: Optional[int]) -> int:
+        """How many layer groups the backward pass is cut into for the gradient exchange (1 = one all-reduce of the whole flat
+        gradient between the backward graph and the optimizer graph).  Bucketing overlaps the exchange of a finished group with
+        the backward pass of the next one; it needs the grouped dW GEMM (bf16 mode).  Default (None, or DG_DP_BUCKETS): bucket
+        when the gradient is large enough for the exchange to matter against the step -- >= 128 MB, i.e. the GPT-2 shapes
+        (652 MB / 1.6 GB) -- and not for the 43 MB of the scaled model, whose whole exchange is ~0.4 ms over xGMI while every
+        cut costs a graph seam and a less well filled dW launch."""
+        import os
+        if arg is None and os.environ.get("DG_DP_BUCKETS"):
+            arg = int(os.environ["DG_DP_BUCKETS"])
+        if not self.grouped_dw or (self.world == 1 and arg is None):
+            return 1
+        if arg is None:
+            arg = 4 if self.n_active * 4 >= (128 << 20) else 1
+        return max(1, min(int(arg), self.L))
+
+    def _dp_plan(self):
+        """[(layers of the group, in backward order; [(lo, hi) ranges of the flat gradient that are final after the group])].
+        Region A is laid out layer 0 .. L-1 then lm_head, so a group's weight gradients are ONE contiguous range; the first group
+        also carries lm_head.weight (its dW problem is the first one recorded), the last group the biases / LayerNorm vectors
+        and the embeddings (B | E: contiguous, final only after the last LayerNorm backward and the embedding backward)."""
+        nb, L = self.dp_buckets, self.L
+        per = (L + nb - 1) // nb
+        plan = []
+        hi_layer = L
+        while hi_layer > 0:
+            lo_layer = max(0, hi_layer - per)
+            lo = self.offA + self.layA.entries[f"{lo_layer}.wqkv"][0]
+            hi = self.offA + (self.layA.size if hi_layer == L else self.layA.entries[f"{hi_layer}.wqkv"][0])
+            ranges = [(lo, hi)]
+            if lo_layer == 0:
+                ranges.append((self.offB, self.n_active))
+            plan.append((list(range(hi_layer - 1, lo_layer - 1, -1)), ranges))
+            hi_layer = lo_layer
+        return plan
 
     def _region(self, key: str):
         for lay, base in ((self.layA, self.offA), (self.layB, self.offB), (self.layE, self.offE), (self.layZ, self.offZ)):
@@ -238,11 +298,19 @@ class TrainEngine:
         self.gflat = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
         self.m_ = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
         self.v_ = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
-        self.tn_workspace = None
+        self.tn_workspaces: Dict[int, Tensor] = {}      # split-K workspace of the grouped dW GEMM, one per launch group
+        self.small_dw: Dict[str, Tuple[Tensor, int]] = {}
         # one-hot rows of the batch (bf16 [M, V rounded up to 8]): rewritten by every forward, read by the grouped dW GEMM
         self.onehot = None
         if self.grouped_dw and ops.layernorm_bwd_fused_supported(self.C) and (self.C // 4) * 8 >= S.pad_to(self.V, 8):
             self.onehot = torch.zeros((self.M, S.pad_to(self.V, 8)), dtype=torch.bfloat16, device=dev)
+        if self.dp_buckets > 1:
+            # bucketed step: few-tile problems leave the grouped launches (see FlatSink.matrix)
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+            for key, P, Q in (("lm.w", self.V, self.C),) + ((("tok", self.V, self.C),) if self.onehot is not None else ()):
+                if ((P + 255) // 256) * ((Q + 127) // 128) <= 4:
+                    n = max(1, min(64, self.M // 256, ncu // (((P + 127) // 128) * ((Q + 127) // 128))))
+                    self.small_dw[key] = (torch.zeros((n, P * Q), dtype=torch.float32, device=dev), n)
         self.slabs = None if self.grouped_dw else torch.zeros((self.S, self.layA.size), dtype=torch.float32, device=dev)
         # partial rows of the bias / LayerNorm gradients: G row chunks, or as many as the GEMM epilogue that emits the column
         # sums (FeedForward's first bias) asks for; rows a producer never writes stay zero
@@ -341,43 +409,55 @@ class TrainEngine:
         rows = ops.cross_entropy(logits, y_idx.view(M), self.V, dlogits=dlogits, grad_scale=1.0 / M)
         return logits, rows, (saved, xa, dlogits)
 
-    def _backward(self, run: S.Run, x_idx: Tensor, ctx):
+    def _backward_begin(self, run: S.Run, x_idx: Tensor, ctx) -> dict:
         saved, xa, dlogits = ctx
+        st = dict(run=run, x_idx=x_idx, saved=saved, sink=FlatSink(self), g_next=None, g0=None)
+        st["dh"] = S.linear_bwd_from_act(run, (xa,), dlogits[:, :self.V], self.param_view("lm.w"), True, st["sink"], {"w": "lm.w", "b": "lm.b"})
+        return st
+
+    def _backward_layers(self, st: dict, layers) -> None:
+        """backward of the given blocks (descending).  st["g_next"]: dropout-backward of dh for the sub-layer that runs next,
+        fused into the LayerNorm backward that produced dh"""
+        run, sink, saved, x_idx = st["run"], st["sink"], st["saved"], st["x_idx"]
         B, T = x_idx.shape
         p = self.p_drop
-        sink = FlatSink(self)
-        dh = S.linear_bwd_from_act(run, (xa,), dlogits[:, :self.V], self.param_view("lm.w"), True, sink, {"w": "lm.w", "b": "lm.b"})
-        g_next = None            # dropout-backward of dh for the sub-layer that runs next, fused into the LN backward
-        for l in reversed(range(self.L)):
+        dh, g_next = st["dh"], st["g_next"]
+        for l in layers:
             P = self._layer_params(l)
             sa, sf = saved[l]
             dh, g_next = S.ffn_bwd(run, sf, dh, P["ln2w"], P["w1"], P["w2"], True, p, l, sink,
                                    {"w1": f"{l}.w1", "b1": f"{l}.b1", "w2": f"{l}.w2", "b2": f"{l}.b2", "ln_w": f"{l}.ln2w", "ln_b": f"{l}.ln2b"},
                                    g_in=g_next, emit=(p, S.site_proj(l), f"{l}.bproj", self.C))
-            emit = (p, S.site_ffn(l - 1), f"{l - 1}.b2", self.C) if l > 0 else (0.0, 0, None, 0)
+            keys = {"wqkv": f"{l}.wqkv", "wproj": f"{l}.wproj", "bproj": f"{l}.bproj", "ln_w": f"{l}.ln1w", "ln_b": f"{l}.ln1b"}
             if l > 0:
-                dh, g_next = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink,
-                                        {"wqkv": f"{l}.wqkv", "wproj": f"{l}.wproj", "bproj": f"{l}.bproj", "ln_w": f"{l}.ln1w", "ln_b": f"{l}.ln1b"},
-                                        g_in=g_next, emit=emit)
+                dh, g_next = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink, keys,
+                                        g_in=g_next, emit=(p, S.site_ffn(l - 1), f"{l - 1}.b2", self.C))
             elif self.onehot is not None:
                 # first block: also take dx in bf16 (no dropout, no bias behind it) -- the X operand of the token-table problem
-                dh, g0 = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink,
-                                    {"wqkv": f"{l}.wqkv", "wproj": f"{l}.wproj", "bproj": f"{l}.bproj", "ln_w": f"{l}.ln1w", "ln_b": f"{l}.ln1b"},
-                                    g_in=g_next, emit=(0.0, 0, None, self.C))
+                dh, st["g0"] = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink, keys,
+                                          g_in=g_next, emit=(0.0, 0, None, self.C))
             else:
-                dh = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink,
-                                {"wqkv": f"{l}.wqkv", "wproj": f"{l}.wproj", "bproj": f"{l}.bproj", "ln_w": f"{l}.ln1w", "ln_b": f"{l}.ln1b"},
-                                g_in=g_next)
+                dh = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink, keys, g_in=g_next)
+        st["dh"], st["g_next"] = dh, g_next
+
+    def _backward_end(self, st: dict, group: int = 0) -> None:
+        x_idx, dh, sink = st["x_idx"], st["dh"], st["sink"]
+        B, T = x_idx.shape
         if self.onehot is not None:
-            sink.defer("tok", self.onehot[:, :self.V], g0, self.V, self.C)
+            S.weight_grad(sink, "tok", self.onehot[:, :self.V], st["g0"], self.V, self.C)
             ops.embed_bwd(x_idx, dh.view(B, T, self.C), None, self.grad_view("pos")[:T], V=self.V)
         else:
             ops.embed_bwd(x_idx, dh.view(B, T, self.C), self.grad_view("tok"), self.grad_view("pos")[:T])
         if self.grouped_dw:
-            sink.flush()
+            sink.flush(group)
         else:
             ops.reduce_partials(self.slabs, self.layA.size, self.S, self.gflat[self.offA:], self.layA.size)
         ops.reduce_partials(self.vparts, self.layB.size, self.Gv, self.gflat[self.offB:], self.layB.size)
+
+    def _backward(self, run: S.Run, x_idx: Tensor, ctx):
+        st = self._backward_begin(run, x_idx, ctx)
+        self._backward_layers(st, reversed(range(self.L)))
+        self._backward_end(st)
 
     def _prog_fwd_bwd(self):
         """gather the batch, forward, backward, reduce the gradient partials"""
@@ -389,6 +469,37 @@ class TrainEngine:
             self.last_logits = logits
         ops.reduce_sum(rows, 1.0 / self.M, out=self.loss)
         self._backward(run, self.x, ctx)
+
+    def _prog_segments(self):
+        """the same step cut at the layer-group boundaries of _dp_plan(): segment k ends with the grouped dW launch of its
+        group, after which the group's range of the flat gradient is final and its all-reduce can start"""
+        plan = self._dp_plan()
+        st = {}
+
+        def first():
+            if self.corpus is not None:
+                ops.batch_gather(self.corpus, self.offsets, self.T, self.x, self.y)
+            run = S.Run(act=self.act, rng=self.state if self.p_drop > 0.0 else None, weights=self.weights)
+            logits, rows, ctx = self._forward(run, self.x, self.y, True)
+            if self.keep_logits:
+                self.last_logits = logits
+            ops.reduce_sum(rows, 1.0 / self.M, out=self.loss)
+            st.clear()
+            st.update(self._backward_begin(run, self.x, ctx))
+
+        segs = []
+        for k, (layers, _) in enumerate(plan):
+            def seg(k=k, layers=layers):
+                if k == 0:
+                    first()
+                self._backward_layers(st, layers)
+                if k == len(plan) - 1:
+                    self._backward_end(st, group=k)
+                    st.clear()                      # release the activations (they live in the graph pool anyway)
+                else:
+                    st["sink"].flush(k)
+            segs.append(seg)
+        return segs, [r for _, r in plan]
 
     def _prog_update(self):
         ops.adamw_step(self.flat, self.gflat, self.m_, self.v_, self.hyper, self.state, 1.0 / self.world,
@@ -404,13 +515,26 @@ class TrainEngine:
             import torch.distributed as dist
             dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)     # mean = sum * 1/world in AdamW
 
+    def _allreduce_ranges_async(self, ranges, works: list) -> None:
+        """start the SUM all-reduce of finished ranges of the flat gradient.  RCCL enqueues it on its own stream behind the work
+        already submitted to the current stream (the segment that produced the ranges) and it then runs beside the next
+        segment; `works` are joined before the optimizer graph."""
+        if self._dp():
+            import torch.distributed as dist
+            for lo, hi in ranges:
+                works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
     # -------------------------------------------------------------------------------- capture
     def _capture(self):
         snap = (self.flat.clone(), self.m_.clone(), self.v_.clone(), self.state.clone())
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):       # warm-up: loads every code object before capture
-            self._prog_fwd_bwd()
+        with torch.cuda.stream(side):       # warm-up: loads every code object and allocates the dW workspaces before capture
+            if self._dp() and self.dp_buckets > 1:
+                for seg in self._prog_segments()[0]:
+                    seg()
+            else:
+                self._prog_fwd_bwd()
             self._prog_update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(self.dev)
@@ -423,6 +547,19 @@ class TrainEngine:
                 self._prog_fwd_bwd()
                 self._prog_update()
             self._graphs = (g,)
+        elif self.dp_buckets > 1:
+            # one graph per layer group + the optimizer graph, all in one memory pool (activations cross the seams)
+            segs, self._seg_ranges = self._prog_segments()
+            graphs = []
+            for seg in segs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=graphs[0].pool() if graphs else None):
+                    seg()
+                graphs.append(g)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=graphs[0].pool()):
+                self._prog_update()
+            self._graphs = tuple(graphs) + (g,)
         else:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
@@ -469,19 +606,58 @@ class TrainEngine:
     def step(self) -> Tensor:
         """one training iteration on the current offsets / batch; returns the device loss scalar"""
         if not self.use_graph:
-            self._prog_fwd_bwd()
-            self._allreduce()
+            if self._dp() and self.dp_buckets > 1:
+                segs, ranges = self._prog_segments()
+                works = []
+                for seg, r in zip(segs, ranges):
+                    seg()
+                    self._allreduce_ranges_async(r, works)
+                for w in works:
+                    w.wait()
+            else:
+                self._prog_fwd_bwd()
+                self._allreduce()
             self._prog_update()
             return self.loss
         if self._graphs is None:
             self._capture()
         if not self._dp():
             self._graphs[0].replay()
+        elif self.dp_buckets > 1:
+            works = []
+            ev = self._timing_events(3)
+            for g, r in zip(self._graphs[:-1], self._seg_ranges):
+                g.replay()
+                self._allreduce_ranges_async(r, works)
+            if ev: ev[1].record()
+            for w in works:
+                w.wait()                    # stream-level join with the RCCL stream (no host block with the nccl backend)
+            if ev: ev[2].record()
+            self._graphs[-1].replay()
+            self._timing_done(ev, ("backward_graphs", "exposed_exchange", "optimizer_graph"))
         else:
+            ev = self._timing_events(3)
             self._graphs[0].replay()
+            if ev: ev[1].record()
             self._allreduce()
+            if ev: ev[2].record()
             self._graphs[1].replay()
+            self._timing_done(ev, ("backward_graph", "exchange", "optimizer_graph"))
         return self.loss
+
+    def _timing_events(self, n: int):
+        if not self.debug_timing:
+            return None
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        return ev
+
+    def _timing_done(self, ev, names) -> None:
+        """debug_timing: where a multi-rank step spends its time (one host sync; never on in a timed run)"""
+        if ev:
+            ev[-1].record()
+            ev[-1].synchronize()
+            self.last_timing = {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}
 
     @torch.no_grad()
     def eval_loss(self, x: Tensor, y: Tensor) -> Tensor:
@@ -533,8 +709,9 @@ class TrainEngine:
     def check_status(self) -> None:
         """raise if a bounded device-side wait of the grouped dW GEMM ever ran out (dg_gemm_tn_grouped: the sticky error word in
         the last 16 bytes of its workspace).  One device round trip: for tests / end-of-run checks, not for every step."""
-        if self.tn_workspace is not None and int(self.tn_workspace[-16:].view(torch.int32)[0].item()) != 0:
-            raise RuntimeError("dg_gemm_tn_grouped: a split-K hand-over timed out; weight gradients since then are invalid")
+        for ws in self.tn_workspaces.values():
+            if int(ws[-16:].view(torch.int32)[0].item()) != 0:
+                raise RuntimeError("dg_gemm_tn_grouped: a split-K hand-over timed out; weight gradients since then are invalid")
 
     def step_count(self) -> int:
         return int(self.state[2].item())
