@@ -269,6 +269,7 @@ def kernel_roofline(eng, offsets, peak_tflops):
             elif opts == [True, False, False, True, True, False, False]: epi = 3
             elif to == "bf16" and opts == [False, False, False, False, False, True, False]: epi = 6 if has("colsum_part") else 4
             elif to == "float" and opts == [True, False, False, False, False, False, False]: epi = 5
+            elif opts == [True, False, False, False, True, False, False]: epi = 7
             else: epi = 0
             sym = f"gemm_nt_ws_kernel<{to},{'true' if pf else 'false'},{nj},{epi}>"      # dispatch rule of dg_gemm_nt
         else:
