@@ -16,7 +16,9 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdrakegpt_hip.so")
 
 DG_F32 = 0
 DG_BF16 = 1
-ABI_VERSION = 4
+DG_FP8_E4M3 = 2
+DG_FP8_E5M2 = 3
+ABI_VERSION = 5
 
 
 class GemmNtArgs(C.Structure):
@@ -40,6 +42,9 @@ class GemmNtArgs(C.Structure):
         ("colsum_part", C.c_void_p),
         ("colsum_ld", C.c_int64),
         ("colsum_rows", C.c_int32),
+        ("b_dtype", C.c_int32),
+        ("scale_a", C.c_void_p),
+        ("scale_b", C.c_void_p),
     ]
 
 
@@ -70,6 +75,8 @@ SIGNATURES = {
     "dg_gemm_nt_colsum_supported": [C.POINTER(GemmNtArgs)],
     "dg_gemm_nt_colsum_rows": [C.POINTER(GemmNtArgs)],
     "dg_gemm_nt_sign_bits_bytes": [_i, _i],
+    "dg_fp8_amax": [_vp, _i, _i64, _vp, _i, _vp, _vp],
+    "dg_fp8_quantize": [_vp, _i, _vp, _i, _i64, _vp, _i, _vp, _vp, _vp],
     "dg_gemm_tn": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp],
     "dg_gemm_tn_grouped": [C.POINTER(TnProblem), _i, _i, _vp, _i64, _vp],
     "dg_gemm_tn_grouped_workspace_bytes": [C.POINTER(TnProblem), _i],

@@ -27,6 +27,8 @@ SOURCES = [
     "elementwise.hip",
     "layernorm.hip",
     "gemm.hip",
+    "gemm_fp8.hip",
+    "fp8.hip",
     "attention.hip",
     "attention_simple.hip",
     "attention_mfma.hip",
@@ -53,7 +55,7 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = True) -
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(PKG, "..", "include", "drakegpt_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_nt_ws.h"), os.path.join(PKG, "..", "include", "drakegpt_hip.h")]
     hdr_digest = _digest(headers)
     flags = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17",
              "-Wno-unused-result", "-I", os.path.join(PKG, "..", "include")]

@@ -1,0 +1,129 @@
+// fp8 operand preparation for the block-scaled MFMA GEMM path (precision = "fp8", BASELINE.json configs[4]).
+// OCP encodings (gfx950): e4m3fn (max 448) for forward operands, e5m2 (max 57344) for gradients.
+// Per-tensor scaling, just in time: amax(x) -> scale = FMAX / amax -> q = cvt_fp8(x * scale) and the dequantisation factor
+// 1 / scale goes to the GEMM epilogue (dg_gemm_nt: scale_a, scale_b).  The reference has no reduced precision at all (every
+// nn.Linear of src/model_component.py:320-325,392-393,404,454 is fp32); this path replaces the operand type of those
+// contractions, nothing else.  HBM-bound: 2 B read + 1 B written per element (+ 2 B read for the amax pass).
+#include "common.h"
+
+#define FP8_E4M3_MAX 448.0f
+#define FP8_E5M2_MAX 57344.0f
+
+// ---------------------------------------------------------------------------------------------
+// amax[seg] = max |x| over segment seg of a flat buffer (atomic max on the bit pattern: non-negative floats order like
+// unsigned integers).  amax must be zero-filled by the caller before the launch (dg_fp8_amax does it).
+// seg table: n_seg x 2 int64 {first element (multiple of 8), number of elements (multiple of 8)}; NULL = one segment.
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_amax_kernel(const T* __restrict__ x, int64_t n, const int64_t* __restrict__ seg, int n_seg,
+                                                       float* __restrict__ amax, int blocks_per_seg) {
+    const int s = seg ? blockIdx.x / blocks_per_seg : 0;
+    const int64_t first = seg ? seg[2 * s] : 0, len = seg ? seg[2 * s + 1] : n;
+    const int b = seg ? blockIdx.x % blocks_per_seg : blockIdx.x;
+    const int nb = seg ? blocks_per_seg : gridDim.x;
+    float m = 0.f;
+    constexpr int V = 16 / sizeof(T);
+    typedef T TV __attribute__((ext_vector_type(V)));
+    const int64_t nv = len / V;
+    const TV* xv = (const TV*)(x + first);
+    for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < nv; i += (int64_t)nb * 256) {
+        const TV v = xv[i];
+#pragma unroll
+        for (int e = 0; e < V; ++e) m = fmaxf(m, fabsf((float)v[e]));
+    }
+    for (int64_t i = nv * V + (int64_t)b * 256 + threadIdx.x; i < len; i += (int64_t)nb * 256) m = fmaxf(m, fabsf((float)x[first + i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax((unsigned int*)(amax + s), __float_as_uint(m));
+}
+
+__global__ void fp8_zero_kernel(float* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
+extern "C" int dg_fp8_amax(const void* x, int dtype, int64_t n, const int64_t* seg, int n_seg, float* amax, void* stream) {
+    if (!x || !amax || n <= 0 || (seg && n_seg <= 0) || !dg_aligned16(x)) return DG_ERR_ARG;
+    if (dtype != DG_BF16 && dtype != DG_F32) return DG_ERR_DTYPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int ns = seg ? n_seg : 1;
+    hipLaunchKernelGGL(fp8_zero_kernel, dim3((ns + 255) / 256), dim3(256), 0, s, amax, ns);
+    int bps = 0, grid;
+    if (seg) {
+        bps = (int)((n / ns + 256 * 64 - 1) / (256 * 64));        // ~64 vector loads per thread on an average segment
+        if (bps < 1) bps = 1; if (bps > 64) bps = 64;
+        grid = bps * ns;
+    } else {
+        int64_t g = (n + 256 * 64 - 1) / (256 * 64);
+        grid = (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+    }
+    if (dtype == DG_BF16) hipLaunchKernelGGL(fp8_amax_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, n, seg, ns, amax, bps);
+    else hipLaunchKernelGGL(fp8_amax_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, n, seg, ns, amax, bps);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// q = cvt(clamp(x * scale)), scale = FMAX / amax (amax == 0: scale 1); scale_inv[seg] = 1 / scale is written by block 0 of
+// the segment for the consumer.  Eight elements per thread: 16 B in (bf16) / 2 x 16 B (f32), 8 B out.
+__device__ __forceinline__ float fp8_scale_of(float amax, float fmax) { return amax > 0.f ? fmax / amax : 1.f; }
+
+template <typename T, bool BF8>
+__global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__ x, uint8_t* __restrict__ q, int64_t n,
+                                                           const int64_t* __restrict__ seg, int n_seg, const float* __restrict__ amax,
+                                                           float* __restrict__ scale_inv, int blocks_per_seg) {
+    const int s = seg ? blockIdx.x / blocks_per_seg : 0;
+    const int64_t first = seg ? seg[2 * s] : 0, len = seg ? seg[2 * s + 1] : n;
+    const int b = seg ? blockIdx.x % blocks_per_seg : blockIdx.x;
+    const int nb = seg ? blocks_per_seg : gridDim.x;
+    const float fmax = BF8 ? FP8_E5M2_MAX : FP8_E4M3_MAX;
+    const float sc = fp8_scale_of(amax[s], fmax);
+    if (b == 0 && threadIdx.x == 0 && scale_inv) scale_inv[s] = 1.f / sc;
+    const int64_t n8 = len / 8;
+    for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < n8; i += (int64_t)nb * 256) {
+        float v[8];
+        if constexpr (sizeof(T) == 2) {
+            const bf16x8 t = *(const bf16x8*)(x + first + i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+        } else {
+            const f32x4 t0 = *(const f32x4*)(x + first + i * 8), t1 = *(const f32x4*)(x + first + i * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[4 + e] = t1[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e] * sc, -fmax), fmax);
+        int lo = 0, hi = 0;
+        if (BF8) {
+            lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], lo, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], lo, true);
+            hi = __builtin_amdgcn_cvt_pk_bf8_f32(v[4], v[5], hi, false); hi = __builtin_amdgcn_cvt_pk_bf8_f32(v[6], v[7], hi, true);
+        } else {
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+        }
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        *(i32x2*)(q + first + i * 8) = (i32x2){lo, hi};
+    }
+}
+
+extern "C" int dg_fp8_quantize(const void* x, int dtype, void* q, int fmt, int64_t n, const int64_t* seg, int n_seg,
+                               const float* amax, float* scale_inv, void* stream) {
+    if (!x || !q || !amax || n <= 0 || n % 8 || (seg && n_seg <= 0) || !dg_aligned16(x) || (((uintptr_t)q) & 7)) return DG_ERR_ARG;
+    if (dtype != DG_BF16 && dtype != DG_F32) return DG_ERR_DTYPE;
+    if (fmt != DG_FP8_E4M3 && fmt != DG_FP8_E5M2) return DG_ERR_DTYPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int ns = seg ? n_seg : 1;
+    int bps = 0, grid;
+    if (seg) {
+        bps = (int)((n / ns + 256 * 32 - 1) / (256 * 32));
+        if (bps < 1) bps = 1; if (bps > 128) bps = 128;
+        grid = bps * ns;
+    } else {
+        int64_t g = (n / 8 + 256 * 4 - 1) / (256 * 4);
+        grid = (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+    }
+#define Q_LAUNCH(T, BF8) hipLaunchKernelGGL((fp8_quantize_kernel<T, BF8>), dim3(grid), dim3(256), 0, s, (const T*)x, (uint8_t*)q, n, seg, ns, amax, scale_inv, bps)
+    if (dtype == DG_BF16) { if (fmt == DG_FP8_E5M2) Q_LAUNCH(bf16_t, true); else Q_LAUNCH(bf16_t, false); }
+    else { if (fmt == DG_FP8_E5M2) Q_LAUNCH(float, true); else Q_LAUNCH(float, false); }
+#undef Q_LAUNCH
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}

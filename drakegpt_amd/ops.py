@@ -13,18 +13,19 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import DG_BF16, DG_F32, GemmNtArgs, check, lib
+from ._lib import DG_BF16, DG_F32, DG_FP8_E4M3, DG_FP8_E5M2, GemmNtArgs, check, lib
 
 Tensor = torch.Tensor
 
-_DT = {torch.float32: DG_F32, torch.bfloat16: DG_BF16}
+_DT = {torch.float32: DG_F32, torch.bfloat16: DG_BF16, torch.float8_e4m3fn: DG_FP8_E4M3, torch.float8_e5m2: DG_FP8_E5M2}
+FP8_DTYPES = (torch.float8_e4m3fn, torch.float8_e5m2)
 
 
 def dt_code(dtype: torch.dtype) -> int:
     try:
         return _DT[dtype]
     except KeyError:
-        raise TypeError(f"drakegpt_amd: unsupported dtype {dtype} (float32 / bfloat16 only)") from None
+        raise TypeError(f"drakegpt_amd: unsupported dtype {dtype} (float32 / bfloat16 / OCP float8 only)") from None
 
 
 def _stream() -> int:
@@ -180,13 +181,22 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
             bias: Optional[Tensor] = None, relu: bool = False, relu_mask: Optional[Tensor] = None,
             residual: Optional[Tensor] = None, dropout_p: float = 0.0, rng_state: Optional[Tensor] = None,
             site: int = 0, out: Optional[Tensor] = None, sign_bits_out: Optional[Tensor] = None,
-            sign_bits: Optional[Tensor] = None, colsum_part: Optional[Tensor] = None) -> Tensor:
+            sign_bits: Optional[Tensor] = None, colsum_part: Optional[Tensor] = None,
+            scale_a: Optional[Tensor] = None, scale_b: Optional[Tensor] = None) -> Tensor:
     """out[M,N] = epilogue(A[M,K] @ Bm[N,K]^T).  A/Bm may carry padding columns beyond K (ld > K).
+    fp8: A float8_e4m3fn (activations) or float8_e5m2 (gradients), Bm float8_e4m3fn, scale_a / scale_b the device scalars
+    fp8_quantize returned (out = epilogue(scale_a * scale_b * A @ Bm^T)); K % 128 == 0.
     sign_bits_out / sign_bits: opaque uint8 buffer (new_sign_bits) holding one bit per element, out > 0.
     colsum_part: fp32 [gemm_nt_colsum_rows(...), N] (rows may be strided): partial rows of the column sums of out."""
     _chk(A, "A", contiguous=False)
     _chk(Bm, "B", contiguous=False)
-    if A.dtype != Bm.dtype:
+    fp8 = A.dtype in FP8_DTYPES
+    if fp8:
+        if Bm.dtype != torch.float8_e4m3fn or scale_a is None or scale_b is None:
+            raise TypeError("gemm_nt: fp8 operands need a float8_e4m3fn B operand and both dequantisation scales")
+        _chk(scale_a, "scale_a", torch.float32)
+        _chk(scale_b, "scale_b", torch.float32)
+    elif A.dtype != Bm.dtype:
         raise TypeError(f"gemm_nt: operand dtypes differ ({A.dtype} vs {Bm.dtype})")
     M = A.shape[0]
     K = A.shape[1] if K is None else K
@@ -199,6 +209,8 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
     a.C, a.ldc = _p(out), _ld(out)
     a.M, a.N, a.K = M, N, K
     a.in_dtype, a.out_dtype = dt_code(A.dtype), dt_code(out.dtype)
+    if fp8:
+        a.b_dtype, a.scale_a, a.scale_b = dt_code(Bm.dtype), _p(scale_a), _p(scale_b)
     if bias is not None:
         _chk(bias, "bias", torch.float32)
         if bias.numel() != N:
@@ -206,6 +218,8 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
     a.bias = _p(bias)
     a.relu = 1 if relu else 0
     if relu_mask is not None:
+        if fp8:
+            raise TypeError("gemm_nt: the tensor-valued relu_mask is not offered for fp8 operands (use sign_bits)")
         _chk(relu_mask, "relu_mask", A.dtype, contiguous=False)
         a.relu_mask, a.ldmask = _p(relu_mask), _ld(relu_mask)
     if residual is not None:
@@ -228,22 +242,49 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
     return out
 
 
-def gemm_nt_sign_bits_supported(dtype: torch.dtype, N: int, K: int) -> bool:
-    """can dg_gemm_nt emit / consume the one-bit-per-element ReLU mask for this problem?"""
+def gemm_nt_sign_bits_supported(dtype: torch.dtype, N: int, K: int, in_dtype: Optional[torch.dtype] = None) -> bool:
+    """can dg_gemm_nt emit / consume the one-bit-per-element ReLU mask for this problem?  (dtype: output / activation type;
+    in_dtype: operand type when it differs -- the fp8 forms)"""
     a = GemmNtArgs()
     a.M, a.N, a.K = 128, N, K
-    a.in_dtype = a.out_dtype = dt_code(dtype)
+    a.out_dtype = dt_code(dtype)
+    a.in_dtype = dt_code(in_dtype or dtype)
     return bool(lib.dg_gemm_nt_sign_bits_supported(C.byref(a)))
 
 
-def gemm_nt_colsum_rows(dtype: torch.dtype, M: int, N: int, K: int) -> int:
+def gemm_nt_colsum_rows(dtype: torch.dtype, M: int, N: int, K: int, in_dtype: Optional[torch.dtype] = None) -> int:
     """partial rows the sign_bits-consuming dg_gemm_nt of this shape writes into colsum_part (0: column sums not offered)"""
     a = GemmNtArgs()
     a.M, a.N, a.K = M, N, K
-    a.in_dtype = a.out_dtype = dt_code(dtype)
+    a.out_dtype = dt_code(dtype)
+    a.in_dtype = dt_code(in_dtype or dtype)
     a.ldc = N
     a.sign_bits = 16        # any non-null, aligned pointer value: the query only looks at which operands are present
     return int(lib.dg_gemm_nt_colsum_rows(C.byref(a)))
+
+
+def fp8_quantize(x: Tensor, fmt: torch.dtype, seg: Optional[Tensor] = None, n_seg: int = 0, out: Optional[Tensor] = None,
+                 scale_inv: Optional[Tensor] = None, amax: Optional[Tensor] = None):
+    """per-tensor (per-segment) just-in-time scaling: q = fp8(x * FMAX / amax(x)) and the dequantisation factor amax / FMAX.
+    x: contiguous bf16 / fp32, numel % 8 == 0.  seg: int64 device table [n_seg, 2] {first element, count} over x.view(-1)
+    (all weight matrices of a step in two launches).  Returns (q with x's shape and dtype `fmt`, scale_inv [n_seg or 1])."""
+    _chk(x, "x")
+    if fmt not in FP8_DTYPES:
+        raise TypeError("fp8_quantize: fmt must be torch.float8_e4m3fn or torch.float8_e5m2")
+    ns = n_seg if seg is not None else 1
+    if seg is not None:
+        _chk(seg, "seg", torch.int64)
+    if out is None:
+        out = torch.empty(x.shape, dtype=fmt, device=x.device)
+    if scale_inv is None:
+        scale_inv = torch.empty((ns,), dtype=torch.float32, device=x.device)
+    if amax is None:
+        amax = torch.empty((ns,), dtype=torch.float32, device=x.device)
+    n = x.numel()
+    check(lib.dg_fp8_amax(_p(x), dt_code(x.dtype), n, _p(seg), ns, _p(amax), _stream()), "dg_fp8_amax")
+    check(lib.dg_fp8_quantize(_p(x), dt_code(x.dtype), _p(out), dt_code(fmt), n, _p(seg), ns, _p(amax), _p(scale_inv), _stream()),
+          "dg_fp8_quantize")
+    return out, scale_inv
 
 
 def new_sign_bits(M: int, N: int, device) -> Tensor:

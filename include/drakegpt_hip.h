@@ -36,13 +36,15 @@ extern "C" {
 
 #define DG_F32 0
 #define DG_BF16 1
+#define DG_FP8_E4M3 2      /* OCP e4m3fn (gfx950's fp8; NOT MI300's fnuz encoding), max 448 */
+#define DG_FP8_E5M2 3      /* OCP e5m2, max 57344 */
 
 #define DG_OK 0
 #define DG_ERR_ARG (-1)       /* bad size / null pointer / unsupported combination */
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 4   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 5   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -134,6 +136,13 @@ typedef struct dg_gemm_nt_args {
     float* colsum_part;            /* nullable: [colsum_rows][colsum_ld] fp32, see below */
     int64_t colsum_ld;
     int32_t colsum_rows;           /* rows of colsum_part, >= dg_gemm_nt_colsum_rows(args) */
+    /* fp8 operands (in_dtype = DG_FP8_E4M3 for forward activations or DG_FP8_E5M2 for gradients; b_dtype = DG_FP8_E4M3, the
+     * weight operand): one byte per element, K % 128 == 0, K >= 256, block-scaled MFMA (v_mfma_f32_16x16x128_f8f6f4) with unit
+     * block scales; the per-tensor dequantisation factors *scale_a and *scale_b (device scalars written by dg_fp8_quantize)
+     * multiply the fp32 accumulator before the epilogue.  b_dtype 0 = same as in_dtype (every non-fp8 call). */
+    int32_t b_dtype;
+    const float* scale_a;
+    const float* scale_b;
 } dg_gemm_nt_args;
 int dg_gemm_nt(const dg_gemm_nt_args* args, void* stream);
 int dg_gemm_nt_sign_bits_supported(const dg_gemm_nt_args* args);
@@ -147,6 +156,15 @@ int dg_gemm_nt_sign_bits_supported(const dg_gemm_nt_args* args);
 int dg_gemm_nt_colsum_supported(const dg_gemm_nt_args* args);
 int dg_gemm_nt_colsum_rows(const dg_gemm_nt_args* args);
 int64_t dg_gemm_nt_sign_bits_bytes(int M, int N);
+
+/* fp8 operand preparation (per-tensor scaling, just in time) for dg_gemm_nt's fp8 form -- precision = "fp8".
+ * dg_fp8_amax: amax[s] = max |x| over segment s of the flat buffer x (n elements).  seg = NULL: one segment; else a device table
+ * of n_seg x 2 int64 {first element, element count}, both multiples of 8 (all weight matrices of the step in one launch).
+ * dg_fp8_quantize: q[i] = fp8(clamp(x[i] * FMAX / amax[s])) in format fmt (DG_FP8_E4M3 / DG_FP8_E5M2), one byte per element,
+ * and scale_inv[s] = amax[s] / FMAX (1 when amax is 0), the factor dg_gemm_nt multiplies back.  n % 8 == 0. */
+int dg_fp8_amax(const void* x, int dtype, int64_t n, const int64_t* seg, int n_seg, float* amax, void* stream);
+int dg_fp8_quantize(const void* x, int dtype, void* q, int fmt, int64_t n, const int64_t* seg, int n_seg,
+                    const float* amax, float* scale_inv, void* stream);
 
 /* GEMM "TN": weight gradients, dW[P,Q] = sum_r A[r,P] * B[r,Q]  (A = dY [R,P], B = X [R,Q]).
  * The contraction over the R = B*T rows is split n_splits ways across workgroups; split s

@@ -1,0 +1,162 @@
+"""fp8 path (precision = "fp8", BASELINE.json configs[4]): operand preparation and the block-scaled MFMA GEMM against fp64
+math on the DEQUANTISED operands.  The reference has no reduced precision (every nn.Linear of src/model_component.py:320-325,
+392-393,404,454 is fp32), so the kernel-level oracle is: exact arithmetic on the very fp8 values the kernel multiplies."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+E4, E5 = torch.float8_e4m3fn, torch.float8_e5m2
+FMAX = {E4: 448.0, E5: 57344.0}
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("fmt", [E4, E5])
+@pytest.mark.parametrize("src", [torch.bfloat16, torch.float32])
+def test_fp8_quantize_matches_ocp_rounding(dev, fmt, src):
+    """q = fp8(x * FMAX / amax): the bytes equal torch's OCP conversion (round to nearest even, e4m3fn / e5m2 -- gfx950's
+    encodings, not MI300's fnuz) of the same scaled values, the dequantisation factor is amax / FMAX, amax lands on +-FMAX."""
+    from drakegpt_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(1000, 264, generator=g) * torch.logspace(-3, 1, 264)).to(src)
+    x[17, 5] = -37.5                                          # the amax element
+    q, sinv = ops.fp8_quantize(x.to(dev), fmt)
+    torch.cuda.synchronize()
+    amax = x.float().abs().max()
+    assert amax.item() == 37.5
+    scale = torch.tensor(FMAX[fmt], dtype=torch.float32) / amax
+    want = (x.float() * scale).clamp(-FMAX[fmt], FMAX[fmt]).to(fmt)
+    assert q.dtype == fmt and q.shape == x.shape
+    assert torch.equal(q.cpu().view(torch.uint8), want.view(torch.uint8))
+    assert abs(sinv.item() - (1.0 / scale).item()) <= 1e-7 * sinv.item()
+    assert q.cpu().float()[17, 5].item() == -FMAX[fmt]
+    # all zeros: scale 1, zeros out
+    z, zs = ops.fp8_quantize(torch.zeros(64, 128, dtype=src, device=dev), fmt)
+    assert zs.item() == 1.0 and torch.all(z.view(torch.uint8) == 0)
+
+
+def test_fp8_quantize_segments(dev):
+    """one launch pair over a flat buffer with a segment table (the weight matrices of a step): per-segment amax and scale"""
+    from drakegpt_amd import ops
+    g = torch.Generator().manual_seed(5)
+    sizes = [384 * 384, 64, 1152 * 384, 80 * 384, 8]
+    gaps = [0, 64, 0, 128, 0]
+    flat, table, pos = [], [], 0
+    for n, gap, amp in zip(sizes, gaps, [0.02, 3.0, 0.5, 1e-4, 100.0]):
+        flat.append(torch.randn(n, generator=g) * amp)
+        table.append([pos, n])
+        pos += n
+        if gap:
+            flat.append(torch.full((gap,), 1e6))             # padding between segments must not leak into any amax
+            pos += gap
+    x = torch.cat(flat).bfloat16()
+    seg = torch.tensor(table, dtype=torch.int64)
+    q, sinv = ops.fp8_quantize(x.to(dev), E4, seg=seg.to(dev), n_seg=len(sizes))
+    torch.cuda.synchronize()
+    for i, (first, n) in enumerate(table):
+        xs = x[first:first + n].float()
+        scale = torch.tensor(448.0) / xs.abs().max()
+        want = (xs * scale).clamp(-448, 448).to(E4)
+        assert torch.equal(q[first:first + n].cpu().view(torch.uint8), want.view(torch.uint8)), i
+        assert abs(sinv[i].item() * scale.item() - 1.0) < 1e-6, i
+
+
+def _rand_fp8(shape, fmt, g, amp):
+    return (torch.randn(*shape, generator=g) * amp).clamp(-FMAX[fmt], FMAX[fmt]).to(fmt)
+
+
+@pytest.mark.parametrize("a_fmt", [E4, E5])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 256), (256, 384, 256), (1000, 1152, 384), (2048, 1024, 4096), (300, 200, 1024), (16384, 192, 256)])
+def test_gemm_nt_fp8_plain(dev, a_fmt, out_dtype, M, N, K):
+    """C = sa * sb * A B^T with e4m3 / e5m2 A and e4m3 B: products of fp8 values are exact in fp32, so only the fp32 accumulation
+    order separates the kernel from fp64 -- 128 x 128 and 128 x 192 tiles, ragged M and N, K = 2 .. 32 steps of 128."""
+    from drakegpt_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = _rand_fp8((M, K), a_fmt, g, 2.0 if a_fmt == E4 else 30.0)
+    B = _rand_fp8((N, K), E4, g, 1.5)
+    sa, sb = torch.tensor([0.0371]), torch.tensor([1.7e-3])
+    ref = (A.double() @ B.double().T) * (sa.double() * sb.double())
+    out = ops.gemm_nt(A.to(dev), B.to(dev), out_dtype, scale_a=sa.to(dev), scale_b=sb.to(dev))
+    torch.cuda.synchronize()
+    assert out.dtype == out_dtype
+    assert rel(out, ref) < (3e-6 if out_dtype == torch.float32 else 3e-3), rel(out, ref)
+
+
+def test_gemm_nt_fp8_asymmetric_identity(dev):
+    """A = I (exact in e4m3) against an asymmetric B: catches a transposed C/D map or a k permutation that differs between the
+    two operands of v_mfma_f32_16x16x128_f8f6f4"""
+    from drakegpt_amd import ops
+    K = 256
+    A = torch.eye(K).to(E4)
+    vals = torch.tensor([0.5, 1.0, 1.5, 2.0, 3.0, -0.75, -4.0, 6.0])
+    B = vals[(torch.arange(96 * K) * 7 % 8)].reshape(96, K) * (1 + (torch.arange(96)[:, None] % 3))
+    Bq = B.to(E4)
+    assert torch.equal(Bq.float(), B)                          # exactly representable
+    one = torch.ones(1, device=dev)
+    out = ops.gemm_nt(A.to(dev), Bq.to(dev), torch.float32, scale_a=one, scale_b=one)
+    assert torch.equal(out.cpu(), B.T.contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 384, 256), (1100, 1024, 512), (256, 1536, 384)])
+def test_gemm_nt_fp8_epilogues(dev, M, N, K):
+    """the epilogue forms the fp8 step uses: bias + ReLU + sign-bit emission (FeedForward's first Linear), the sign-bit-masked
+    dX with column sums (its backward, e5m2 gradients), bias + dropout + residual and bias + residual (proj / second Linear)"""
+    from oracle import rng_ref
+    from drakegpt_amd import ops
+    g = torch.Generator().manual_seed(K)
+    A = _rand_fp8((M, K), E4, g, 2.0)
+    B = _rand_fp8((N, K), E4, g, 1.0)
+    G = _rand_fp8((M, N), E5, g, 20.0)                        # a gradient of the [M, N] output
+    Bt = _rand_fp8((K, N), E4, g, 1.0)                        # "W^T" for the dX direction: [K out, N contraction]
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    sa, sb = torch.tensor([0.01]), torch.tensor([0.02])
+    d = lambda t: t.to(dev)
+    acc = (A.double() @ B.double().T) * (0.01 * 0.02)
+    # bias + ReLU + sign bits, then consume the bits in the dX form
+    sup = ops.gemm_nt_sign_bits_supported(torch.bfloat16, N, K, in_dtype=E4) and ops.gemm_nt_sign_bits_supported(torch.bfloat16, N, K, in_dtype=E5)
+    assert sup and not ops.gemm_nt_sign_bits_supported(torch.bfloat16, N, 192, in_dtype=E4)       # K % 128 == 0, K >= 256
+    if sup:
+        bits = ops.new_sign_bits(M, N, dev)
+        f = ops.gemm_nt(d(A), d(B), torch.bfloat16, bias=d(bias), relu=True, sign_bits_out=bits, scale_a=d(sa), scale_b=d(sb))
+        ref_f = torch.relu(acc + bias.double())
+        assert rel(f, ref_f) < 3e-3
+        # dX of the Linear that consumed f ... here just the masking semantics: out[m, n] = (G2 B2^T)[m, n] where f[m, n] > 0
+        G2 = _rand_fp8((M, K), E5, g, 10.0)
+        B2 = _rand_fp8((N, K), E4, g, 1.0)
+        rows = ops.gemm_nt_colsum_rows(torch.bfloat16, M, N, K, in_dtype=E5)
+        cs = torch.full((max(rows, 1), N), float("nan"), device=dev)
+        out = ops.gemm_nt(d(G2), d(B2), torch.bfloat16, sign_bits=bits, scale_a=d(sa), scale_b=d(sb), colsum_part=cs if rows else None)
+        ref = (G2.double() @ B2.double().T) * (0.01 * 0.02) * (f.double().cpu() > 0)
+        assert rel(out, ref) < 3e-3
+        if rows:
+            assert rel(cs.sum(0), ref.sum(0)) < 1e-4
+    # bias + dropout + residual (fp32 out) with the shared keep-mask, and bias + residual
+    rng = ops.new_rng_state(99, dev, 4)
+    keep = torch.from_numpy(rng_ref.keep_mask(99, 4, 7, 0.2, M * N).reshape(M, N)).double()
+    y = ops.gemm_nt(d(A), d(B), torch.float32, bias=d(bias), dropout_p=0.2, rng_state=rng, site=7, residual=d(resid), scale_a=d(sa), scale_b=d(sb))
+    assert rel(y, (acc + bias.double()) * keep / 0.8 + resid.double()) < 3e-6
+    y0 = ops.gemm_nt(d(A), d(B), torch.float32, bias=d(bias), residual=d(resid), scale_a=d(sa), scale_b=d(sb))
+    assert rel(y0, acc + bias.double() + resid.double()) < 3e-6
+    # e5m2 gradient x e4m3 W^T, plain bf16 out (dX of proj / QKV / first FFN Linear)
+    dx = ops.gemm_nt(d(G), d(Bt), torch.bfloat16, scale_a=d(sa), scale_b=d(sb))
+    assert rel(dx, (G.double() @ Bt.double().T) * (0.01 * 0.02)) < 3e-3
+
+
+def test_gemm_nt_fp8_argument_validation(dev):
+    from drakegpt_amd import ops
+    A = torch.zeros(128, 256, dtype=E4, device=dev)
+    one = torch.ones(1, device=dev)
+    with pytest.raises(TypeError):
+        ops.gemm_nt(A, A, torch.float32)                                        # no scales
+    with pytest.raises(TypeError):
+        ops.gemm_nt(A, A.to(E5), torch.float32, scale_a=one, scale_b=one)       # B must be e4m3
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(A[:, :192].contiguous(), A[:, :192].contiguous(), torch.float32, scale_a=one, scale_b=one)   # K % 128
+    with pytest.raises(RuntimeError):
+        ops.fp8_quantize(torch.zeros(100, 3, dtype=torch.bfloat16, device=dev), E4)                              # numel % 8
