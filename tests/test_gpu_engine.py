@@ -257,7 +257,10 @@ def test_train_harness_on_text_and_on_pt_files(dev, golden_dir, tmp_path, capsys
     import json
     la = [json.loads(l) for l in a.splitlines() if l.startswith("{")]
     lb = [json.loads(l) for l in b.splitlines() if l.startswith("{")]
-    assert len(la) == 2 and [(r["train_loss"], r["val_loss"]) for r in la] == [(r["train_loss"], r["val_loss"]) for r in lb]
+    # (equal up to the fp32 atomics of the token-table scatter-add at this tiny configuration)
+    assert len(la) == 2 and len(lb) == 2
+    for ra, rb in zip(la, lb):
+        assert ra["train_loss"] == pytest.approx(rb["train_loss"], rel=1e-5) and ra["val_loss"] == pytest.approx(rb["val_loss"], rel=1e-5)
     assert all(0 < r["val_loss"] < 6 for r in la) and la[1]["lr"] == pytest.approx(2.6e-3)
     # the sample is decoded with the text's own mapper: characters of the fixture's vocabulary
     fix = torch.load(os.path.join(golden_dir, "corpus_fixture.pt"), weights_only=True)

