@@ -38,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (guides/MI355X_MICROARCH.md: ~2.5 PF)
+PEAK_FP8_TFLOPS = 5000.0       # dense block-scaled fp8 MFMA peak (same guide: ~5 PF)
 PEAK_F32_TFLOPS = 157.3        # fp32 MFMA = vector peak
 PEAK_HBM_GBS = 8000.0
 
@@ -56,7 +57,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="scaled")
     ap.add_argument("--batch", type=int, default=None, help="rows per GPU (default: the preset's batch_size)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -150,7 +151,7 @@ def main():
     tokens = args.steps * B * T * world
     tok_s = tokens / dt
     fpt = flops_per_token(cfg, V)
-    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+    peak = {"bf16": PEAK_BF16_TFLOPS, "fp8": PEAK_FP8_TFLOPS, "fp32": PEAK_F32_TFLOPS}[args.precision]
 
     if rank == 0:
         log(f"{tok_s:.0f} tokens/s, {1e3 * dt / args.steps:.3f} ms/step, loss {final_loss:.4f}")
@@ -162,10 +163,12 @@ def main():
         del eng, model
         torch.cuda.empty_cache()
         extra = {}
-        for name, cname, b, p_drop, st, wu in (("scaled_dropout0", "scaled", B, 0.0, 30, 5), ("scaled_B256", "scaled", 256, None, 20, 5),
-                                               ("gpt2_small_B8", "gpt2_small", 8, None, 8, 3)):
+        for name, cname, b, p_drop, st, wu, prec in (("scaled_dropout0", "scaled", B, 0.0, 30, 5, "bf16"), ("scaled_B256", "scaled", 256, None, 20, 5, "bf16"),
+                                                     ("gpt2_small_B8", "gpt2_small", 8, None, 8, 3, "bf16"),
+                                                     ("gpt2_medium_B8_bf16", "gpt2_medium", 8, None, 5, 2, "bf16"),
+                                                     ("gpt2_medium_B8_fp8", "gpt2_medium", 8, None, 5, 2, "fp8")):
             try:
-                extra[name] = run_extra(cname, b, p_drop, st, wu, dev)
+                extra[name] = run_extra(cname, b, p_drop, st, wu, dev, prec)
                 log(f"extra {name}: {extra[name]['value']:.0f} tokens/s, {extra[name]['ms_per_step']:.3f} ms/step")
             except Exception as e:                     # an extra line must never take the headline line down with it
                 extra[name] = {"error": f"{type(e).__name__}: {e}"}
@@ -180,7 +183,7 @@ def main():
             "metric": "training tokens/sec (fwd+bwd+AdamW)", "value": tok_s, "unit": "tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp8": "fp8", "fp32": "f32"}[args.precision], "data": "synthetic",
             "config": {"workload": f"TransformerLM_{args.config}: V={V} C={cfg['embedding_dim']} T={T} heads={cfg['num_heads']} "
                                    f"layers={cfg['num_layers']} dropout={cfg['dropout']}; fwd+bwd+AdamW; hipGraph={'off' if args.no_graph else 'on'}",
                        "batch_per_gpu": B, "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}", "dp_gradient_buckets": dp_buckets,
@@ -201,9 +204,10 @@ def main():
         dist.destroy_process_group()
 
 
-def run_extra(config_name, B, dropout, steps, warmup, dev):
+def run_extra(config_name, B, dropout, steps, warmup, dev, precision="bf16"):
     """one more single-GPU configuration, timed like the headline region (offsets resident, graph replay, synchronize on
-    both sides); bf16, synthetic corpus, random-init weights (seed 42)"""
+    both sides); synthetic corpus, random-init weights (seed 42).  precision "fp8": the residual blocks' Linears (forward and
+    dX) on e4m3 / e5m2 operands, everything else as "bf16"; its MFMA fraction is quoted against the fp8 peak."""
     import drakegpt_amd as D
     from drakegpt_amd.config import DRAKE_VOCAB_SIZE, PRESETS
     from drakegpt_amd.engine import TrainEngine
@@ -213,7 +217,7 @@ def run_extra(config_name, B, dropout, steps, warmup, dev):
     V = cfg.get("vocab_size", DRAKE_VOCAB_SIZE)
     T = cfg["context_length"]
     torch.manual_seed(42)
-    model = D.TransformerLM(V, cfg["embedding_dim"], T, cfg["num_heads"], cfg["num_layers"], cfg["dropout"], precision="bf16").to(dev)
+    model = D.TransformerLM(V, cfg["embedding_dim"], T, cfg["num_heads"], cfg["num_layers"], cfg["dropout"], precision=precision).to(dev)
     eng = TrainEngine(model, B, T, lr=cfg["base_lr"], betas=cfg["betas"], seed=42)
     n_corpus = 1_000_000 if V <= 256 else 10_000_000
     eng.set_corpus(torch.randint(0, V, (n_corpus,), generator=torch.Generator().manual_seed(42)))
@@ -235,9 +239,10 @@ def run_extra(config_name, B, dropout, steps, warmup, dev):
     del eng, model
     return {"value": tok_s, "unit": "tokens/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
             "workload": f"TransformerLM_{config_name}: V={V} C={cfg['embedding_dim']} T={T} heads={cfg['num_heads']} layers={cfg['num_layers']} "
-                        f"dropout={cfg['dropout']} batch={B}; fwd+bwd+AdamW; bf16; hipGraph=on",
-            "model_flops_per_token": fpt, "achieved_tflops": tok_s * fpt / 1e12,
-            "mfma_peak_frac_whole_step": tok_s * fpt / 1e12 / PEAK_BF16_TFLOPS, "final_loss": loss}
+                        f"dropout={cfg['dropout']} batch={B}; fwd+bwd+AdamW; {precision}; hipGraph=on",
+            "dtype": precision, "model_flops_per_token": fpt, "achieved_tflops": tok_s * fpt / 1e12,
+            "peak_tflops": PEAK_FP8_TFLOPS if precision == "fp8" else PEAK_BF16_TFLOPS,
+            "mfma_peak_frac_whole_step": tok_s * fpt / 1e12 / (PEAK_FP8_TFLOPS if precision == "fp8" else PEAK_BF16_TFLOPS), "final_loss": loss}
 
 
 def kernel_roofline(eng, offsets, peak_tflops):
@@ -258,7 +263,8 @@ def kernel_roofline(eng, offsets, peak_tflops):
         N = kw.get("N") or Bm.shape[0]
         r = real_nt(A, Bm, out_dtype, **kw)
         to = "bf16" if out_dtype == torch.bfloat16 else "float"
-        if A.dtype == torch.bfloat16 and K % 64 == 0 and K >= 128:        # dispatch rule of dg_gemm_nt
+        f8 = A.dtype in (torch.float8_e4m3fn, torch.float8_e5m2)
+        if f8 or (A.dtype == torch.bfloat16 and K % 64 == 0 and K >= 128):        # dispatch rule of dg_gemm_nt
             pf = kw.get("sign_bits") is not None                           # mask-bit prefetch variant
             nj = 6 if N % 192 == 0 else 4                                  # 128 x 192 tiles when they divide N
             has = lambda k: kw.get(k) is not None and kw.get(k) is not False
@@ -271,7 +277,7 @@ def kernel_roofline(eng, offsets, peak_tflops):
             elif to == "float" and opts == [True, False, False, False, False, False, False]: epi = 5
             elif opts == [True, False, False, False, True, False, False]: epi = 7
             else: epi = 0
-            sym = f"gemm_nt_ws_kernel<{to},{'true' if pf else 'false'},{nj},{epi}>"      # dispatch rule of dg_gemm_nt
+            sym = f"gemm_nt_ws_kernel<{to},{'true' if pf else 'false'},{nj},{epi}{',fp8' if f8 else ''}>"      # dispatch rule of dg_gemm_nt
         else:
             sym = f"gemm_nt_kernel<{'bf16' if A.dtype == torch.bfloat16 else 'float'},{to}>"
         kw2 = dict(kw)

@@ -59,12 +59,20 @@ class ShadowWeights:
     def __init__(self):
         self.fwd_map: Dict[int, Tensor] = {}
         self.bwd_map: Dict[int, Tensor] = {}
+        self.fwd8_map: Dict[int, Tuple[Tensor, Tensor]] = {}      # fp8 mode: (e4m3 copy, dequantisation scale [1])
+        self.bwd8_map: Dict[int, Tuple[Tensor, Tensor]] = {}
 
     def fwd(self, W: Tensor) -> Tensor:
         return self.fwd_map[W.data_ptr()]
 
     def bwd(self, W: Tensor) -> Tensor:
         return self.bwd_map[W.data_ptr()]
+
+    def fwd8(self, W: Tensor):
+        return self.fwd8_map[W.data_ptr()]
+
+    def bwd8(self, W: Tensor):
+        return self.bwd8_map[W.data_ptr()]
 
 
 class FlatSink:
@@ -142,6 +150,7 @@ class TrainEngine:
         self.model = model
         self.dev = p0.device
         self.act = model.act_dtype
+        self.fp8 = bool(getattr(model, "fp8", False))
         self.B = int(batch_size)
         self.T = int(context_length or model.context_length)
         if self.T > model.context_length:
@@ -351,7 +360,17 @@ class TrainEngine:
         if self.act == torch.bfloat16:
             self.shadow = torch.zeros(self.n_active, dtype=torch.bfloat16, device=dev)
         self._mats: List[Tuple[Tensor, Tensor]] = []
-        gr = S.granule(self.act)
+        # every W^T lives in ONE flat buffer (like the forward shadows), so that the fp8 mode can quantise all of them with one
+        # segmented launch pair
+        wt_sizes = {key: shape[1] * S.k_pad(shape[0], self.act) for key, (off, shape) in self.layA.entries.items()}
+        self.wt_flat = torch.zeros(sum(_round(n) for n in wt_sizes.values()), dtype=self.act, device=dev)
+        seg_f, seg_b, wt_off = [], [], 0
+        if self.fp8:
+            self.shadow8 = torch.zeros(self.layA.size, dtype=S.E4M3, device=dev)
+            self.wt8_flat = torch.zeros(self.wt_flat.numel(), dtype=S.E4M3, device=dev)
+            n_fp8 = sum(1 for key in self.layA.entries if key != "lm.w")
+            self.wscale_f = torch.ones(n_fp8, dtype=torch.float32, device=dev)
+            self.wscale_b = torch.ones(n_fp8, dtype=torch.float32, device=dev)
         for key, (off, shape) in self.layA.entries.items():
             W = self.param_view(key)
             n = shape[0] * shape[1]
@@ -359,9 +378,21 @@ class TrainEngine:
                 self.weights.fwd_map[W.data_ptr()] = self.shadow[self.offA + off:self.offA + off + n].view(shape)
             else:
                 self.weights.fwd_map[W.data_ptr()] = W
-            Wt = torch.zeros((shape[1], S.k_pad(shape[0], self.act)), dtype=self.act, device=dev)
+            wt_shape = (shape[1], S.k_pad(shape[0], self.act))
+            Wt = self.wt_flat[wt_off:wt_off + wt_sizes[key]].view(wt_shape)
             self.weights.bwd_map[W.data_ptr()] = Wt
             self._mats.append((W, Wt))
+            if self.fp8 and key != "lm.w":                       # lm_head stays bf16 (V is no multiple of the fp8 K step)
+                i = len(seg_f)
+                seg_f.append([off, n])
+                seg_b.append([wt_off, wt_sizes[key]])
+                self.weights.fwd8_map[W.data_ptr()] = (self.shadow8[off:off + n].view(shape), self.wscale_f[i:i + 1])
+                self.weights.bwd8_map[W.data_ptr()] = (self.wt8_flat[wt_off:wt_off + wt_sizes[key]].view(wt_shape), self.wscale_b[i:i + 1])
+            wt_off += _round(wt_sizes[key])
+        if self.fp8:
+            self.seg_f = torch.tensor(seg_f, dtype=torch.int64, device=dev)
+            self.seg_b = torch.tensor(seg_b, dtype=torch.int64, device=dev)
+            self.w_amax = torch.zeros(len(seg_f), dtype=torch.float32, device=dev)
 
     def refresh_shadows(self):
         """bf16 copy of the GEMM weights + every W^T.  Call after the weights change outside step()
@@ -377,6 +408,12 @@ class TrainEngine:
             pairs = [(self.weights.fwd(W) if from_shadow else W, Wt) for W, Wt in self._mats]
             self._tr_table = ops.make_transpose_table(pairs, self.dev)
         ops.transpose_cast_batched(*self._tr_table, self.act, in_dtype=torch.bfloat16 if from_shadow else torch.float32)
+        if self.fp8:
+            # e4m3 copies of every block matrix and of every W^T, per-matrix scales: two launch pairs for the whole model
+            n = self.seg_f.shape[0]
+            ops.fp8_quantize(self.shadow[self.offA:self.offA + self.layA.size], S.E4M3, seg=self.seg_f, n_seg=n, out=self.shadow8,
+                             scale_inv=self.wscale_f, amax=self.w_amax)
+            ops.fp8_quantize(self.wt_flat, S.E4M3, seg=self.seg_b, n_seg=n, out=self.wt8_flat, scale_inv=self.wscale_b, amax=self.w_amax)
 
     # -------------------------------------------------------------------------------- programs
     def _layer_params(self, l: int):
@@ -463,7 +500,7 @@ class TrainEngine:
         """gather the batch, forward, backward, reduce the gradient partials"""
         if self.corpus is not None:
             ops.batch_gather(self.corpus, self.offsets, self.T, self.x, self.y)
-        run = S.Run(act=self.act, rng=self.state if self.p_drop > 0.0 else None, weights=self.weights)
+        run = S.Run(act=self.act, rng=self.state if self.p_drop > 0.0 else None, weights=self.weights, fp8=self.fp8)
         logits, rows, ctx = self._forward(run, self.x, self.y, True)
         if self.keep_logits:
             self.last_logits = logits
@@ -479,7 +516,7 @@ class TrainEngine:
         def first():
             if self.corpus is not None:
                 ops.batch_gather(self.corpus, self.offsets, self.T, self.x, self.y)
-            run = S.Run(act=self.act, rng=self.state if self.p_drop > 0.0 else None, weights=self.weights)
+            run = S.Run(act=self.act, rng=self.state if self.p_drop > 0.0 else None, weights=self.weights, fp8=self.fp8)
             logits, rows, ctx = self._forward(run, self.x, self.y, True)
             if self.keep_logits:
                 self.last_logits = logits
@@ -662,7 +699,7 @@ class TrainEngine:
     @torch.no_grad()
     def eval_loss(self, x: Tensor, y: Tensor) -> Tensor:
         """forward only, dropout off (ref: evaluate_loss, src/train.py:61-75)"""
-        run = S.Run(act=self.act, rng=None, weights=self.weights)
+        run = S.Run(act=self.act, rng=None, weights=self.weights, fp8=self.fp8)
         _, rows, _ = self._forward(run, x, y, False)
         return ops.reduce_sum(rows, 1.0 / rows.numel())
 
@@ -687,7 +724,7 @@ class TrainEngine:
             self.ev_loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
 
             def prog():
-                run = S.Run(act=self.act, rng=None, weights=self.weights)
+                run = S.Run(act=self.act, rng=None, weights=self.weights, fp8=self.fp8)
                 _, rows, _ = self._forward(run, self.ev_x, self.ev_y, False)
                 ops.reduce_sum(rows, 1.0 / rows.numel(), out=self.ev_loss)
             side = torch.cuda.Stream(device=self.dev)

@@ -13,8 +13,11 @@ from . import sublayers as S
 Tensor = torch.Tensor
 
 
-def _run(act: torch.dtype, rng: Optional[Tensor]) -> S.Run:
-    return S.Run(act=act, rng=rng, weights=S.OnTheFlyWeights(act))
+def _run(act, rng: Optional[Tensor]) -> S.Run:
+    """act: the activation dtype, or "fp8" (HipModule.run_mode): bf16 activations, fp8 operands for the block Linears"""
+    fp8 = act == "fp8"
+    dt = torch.bfloat16 if fp8 else act
+    return S.Run(act=dt, rng=rng, weights=S.OnTheFlyWeights(dt), fp8=fp8)
 
 
 class EmbedFn(torch.autograd.Function):

@@ -12,8 +12,9 @@ GEMMs with fused bias/ReLU/dropout/residual epilogues and a wave-per-row LayerNo
 hand-written backward (drakegpt_amd/sublayers.py).  Inputs must live on the GPU: there is no CPU
 path in this package.
 
-precision: "fp32" (default; exact-fp32 MFMA, tracks the reference to ~1e-6) or "bf16" (bf16 MFMA
-operands and stored activations, fp32 accumulation / residual stream / master weights).
+precision: "fp32" (default; exact-fp32 MFMA, tracks the reference to ~1e-6), "bf16" (bf16 MFMA
+operands and stored activations, fp32 accumulation / residual stream / master weights) or "fp8" (as
+"bf16", with the Linears of the residual blocks on OCP fp8 operands: e4m3 forward, e5m2 gradients).
 """
 from __future__ import annotations
 
@@ -25,7 +26,9 @@ import torch.nn as nn
 from . import functional as HF
 from . import ops
 
-_PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16}
+# "fp8": activations are stored as in "bf16"; the operands of the residual blocks' Linears (forward and dX) are quantised to OCP
+# fp8 (e4m3 forward, e5m2 gradients) with per-tensor just-in-time scales for the block-scaled MFMA (BASELINE.json configs[4])
+_PRECISIONS = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp8": torch.bfloat16}
 
 
 class HipModule(nn.Module):
@@ -43,6 +46,15 @@ class HipModule(nn.Module):
     @property
     def act_dtype(self) -> torch.dtype:
         return _PRECISIONS[self.precision]
+
+    @property
+    def fp8(self) -> bool:
+        return self.precision == "fp8"
+
+    @property
+    def run_mode(self):
+        """what the autograd shells hand to sublayers.Run: the activation dtype, or "fp8" (bf16 activations + fp8 GEMM operands)"""
+        return "fp8" if self.fp8 else self.act_dtype
 
     def set_precision(self, precision: str) -> "HipModule":
         if precision not in _PRECISIONS:
@@ -102,7 +114,7 @@ class Head(HipModule):
         _check_width(C, self.act_dtype, "embedding_dim")
         _check_width(3 * self.head_size, self.act_dtype, "3*head_size")
         rng = self._rng_snapshot(x.device, self._p > 0.0)
-        return HF.attention(x, None, None, _pack_qkv([self]), None, None, rng, self.act_dtype, False, 1,
+        return HF.attention(x, None, None, _pack_qkv([self]), None, None, rng, self.run_mode, False, 1,
                             self.head_size, self._p, 0.0, self.layer_index)
 
 
@@ -129,7 +141,7 @@ class _MultiHeadBase(HipModule):
         if rng == "auto":
             rng = self._rng_snapshot(x.device, p > 0.0)
         return HF.attention(x, ln_w, ln_b, _pack_qkv(heads), None if proj is None else proj.weight,
-                            None if proj is None else proj.bias, rng, act, residual, NH, H, p, p, self.layer_index)
+                            None if proj is None else proj.bias, rng, self.run_mode, residual, NH, H, p, p, self.layer_index)
 
     def forward(self, x):
         return self._attend(x)
@@ -175,7 +187,7 @@ class _FeedForwardBase(HipModule):
         if rng == "auto":
             rng = self._rng_snapshot(x.device, p > 0.0)
         return HF.feed_forward(x, ln_w, ln_b, lin1.weight, lin1.bias, None if lin2 is None else lin2.weight,
-                               None if lin2 is None else lin2.bias, rng, act, residual, p, self.layer_index)
+                               None if lin2 is None else lin2.bias, rng, self.run_mode, residual, p, self.layer_index)
 
     def forward(self, x):
         return self._ffn(x)

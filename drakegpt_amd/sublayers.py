@@ -25,6 +25,7 @@ import torch
 from . import ops
 
 Tensor = torch.Tensor
+E4M3, E5M2 = torch.float8_e4m3fn, torch.float8_e5m2       # OCP encodings: forward operands / gradients
 
 
 def site_attn(layer: int) -> int:
@@ -93,6 +94,13 @@ class OnTheFlyWeights:
     def bwd(self, W: Tensor) -> Tensor:
         return ops.transpose_cast(W, self.act, ldo=k_pad(W.shape[0], self.act))
 
+    def fwd8(self, W: Tensor):
+        """(e4m3 copy of W, dequantisation scale) -- quantised per call here; the engine keeps persistent fp8 shadows"""
+        return ops.fp8_quantize(self.fwd(W), E4M3)
+
+    def bwd8(self, W: Tensor):
+        return ops.fp8_quantize(self.bwd(W), E4M3)
+
 
 class LocalSink:
     """Gradient sink of the autograd path: allocates partial buffers, reduces on `finish`."""
@@ -152,9 +160,44 @@ class Run:
     act: torch.dtype                 # GEMM operand / stored activation type
     rng: Optional[Tensor]            # device rng state snapshot; None => no dropout (eval)
     weights: object                  # OnTheFlyWeights | engine.ShadowWeights
+    fp8: bool = False                # precision = "fp8": the block Linears (forward and dX) run on fp8 operands
 
     def p(self, p: float) -> float:
         return p if (self.rng is not None and p > 0.0) else 0.0
+
+
+def fp8_k_ok(k: int) -> bool:
+    """contraction lengths the fp8 GEMM takes (128-element K steps, at least two)"""
+    return k % 128 == 0 and k >= 256
+
+
+def linear_nt(run: Run, x: Tensor, W: Tensor, out_dtype: torch.dtype, **epi) -> Tensor:
+    """forward of a block Linear: epilogue(x W^T), x [M, in] in the activation dtype, W [out, in] the fp32 master.
+    fp8 mode: x is quantised to e4m3 just in time (amax pass + cast pass), W comes as its persistent e4m3 shadow."""
+    if run.fp8 and fp8_k_ok(W.shape[1]) and x.is_contiguous() and x.dtype == torch.bfloat16:
+        wq, ws = run.weights.fwd8(W)
+        xq, xs = ops.fp8_quantize(x, E4M3)
+        return ops.gemm_nt(xq, wq, out_dtype, scale_a=xs, scale_b=ws, **epi)
+    return ops.gemm_nt(x, run.weights.fwd(W), out_dtype, **epi)
+
+
+def linear_dx(run: Run, g: Tensor, W: Tensor, out_dtype: torch.dtype, **epi) -> Tensor:
+    """dX of a block Linear: epilogue(g W), g [M, out] in the activation dtype (a gradient: e5m2 in fp8 mode), W^T shadow
+    [in, out padded]"""
+    K = W.shape[0]
+    if run.fp8 and fp8_k_ok(K) and g.is_contiguous() and g.dtype == torch.bfloat16 and g.shape[1] == K:
+        wq, ws = run.weights.bwd8(W)
+        if wq.shape[1] == K:
+            gq, gs = ops.fp8_quantize(g, E5M2)
+            return ops.gemm_nt(gq, wq, out_dtype, K=K, scale_a=gs, scale_b=ws, **epi)
+    return ops.gemm_nt(g, run.weights.bwd(W), out_dtype, K=K, **epi)
+
+
+def _op_dtype(run: Run, k: int, grad: bool = False):
+    """operand dtype linear_nt / linear_dx will use for a contraction of length k (the sign-bit / column-sum support queries)"""
+    if run.fp8 and fp8_k_ok(k):
+        return E5M2 if grad else E4M3
+    return None
 
 
 def _as_act(run: Run, x2d: Tensor) -> Tensor:
@@ -190,11 +233,11 @@ def attn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tenso
         h, mean, rstd = ops.layernorm_fwd(x2d, ln_w, ln_b, run.act)
     else:
         h, mean, rstd = _as_act(run, x2d), None, None
-    qkv = ops.gemm_nt(h, run.weights.fwd(wqkv), run.act)
+    qkv = linear_nt(run, h, wqkv, run.act)
     o, lse = ops.attn_fwd(qkv, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer))
     if wproj is not None:
-        y = ops.gemm_nt(o, run.weights.fwd(wproj), torch.float32, bias=bproj, dropout_p=run.p(p_proj),
-                        rng_state=run.rng, site=site_proj(layer), residual=x2d if residual else None)
+        y = linear_nt(run, o, wproj, torch.float32, bias=bproj, dropout_p=run.p(p_proj),
+                      rng_state=run.rng, site=site_proj(layer), residual=x2d if residual else None)
     else:
         if residual:
             raise RuntimeError("residual attention without a projection is not a reference configuration")
@@ -217,7 +260,7 @@ def attn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], wqkv: Tensor, 
             g = ops.dropout_bwd_cast(dy, run.act, run.p(p_proj), run.rng, site_proj(layer), colsum_part=part,
                                      part_stride=stride, n_partials=n)
         weight_grad(sink, keys["wproj"], g, o, wproj.shape[0], wproj.shape[1])
-        do = ops.gemm_nt(g, run.weights.bwd(wproj), run.act, K=wproj.shape[0])
+        do = linear_dx(run, g, wproj, run.act)
     else:
         do = _as_act(run, dy)
     dqkv = ops.attn_bwd(qkv, o, do, lse, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer))
@@ -225,10 +268,10 @@ def attn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], wqkv: Tensor, 
     if not need_dx:
         return None
     if ln_w is not None:
-        dh = ops.gemm_nt(dqkv, run.weights.bwd(wqkv), _dh_dtype(run, ln_w), K=wqkv.shape[0])
+        dh = linear_dx(run, dqkv, wqkv, _dh_dtype(run, ln_w))
         dx, g_next = _ln_tail(run, dh, x2d, ln_w, mean, rstd, dy if residual else None, sink, keys, emit)
         return (dx, g_next) if emit is not None else dx
-    dx = ops.gemm_nt(dqkv, run.weights.bwd(wqkv), torch.float32, K=wqkv.shape[0], residual=dy if residual else None)
+    dx = linear_dx(run, dqkv, wqkv, torch.float32, residual=dy if residual else None)
     return (dx, None) if emit is not None else dx
 
 
@@ -245,15 +288,16 @@ def ffn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor
         h, mean, rstd = _as_act(run, x2d), None, None
     if w2 is None:
         # FeedForward: Linear(C,C) + ReLU (ref: src/model_component.py:118-121)
-        y = ops.gemm_nt(h, run.weights.fwd(w1), torch.float32, bias=b1, relu=True)
+        y = linear_nt(run, h, w1, torch.float32, bias=b1, relu=True)
         return y, (x2d, h, mean, rstd, y, None)
     # the ReLU mask for backward travels as one bit per element next to f (1/16 of the bytes the dX GEMM would re-read)
     bits = None
-    if ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w1.shape[1]) and ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w2.shape[0]):
+    if (ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w1.shape[1], in_dtype=_op_dtype(run, w1.shape[1]))
+            and ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w2.shape[0], in_dtype=_op_dtype(run, w2.shape[0], grad=True))):
         bits = ops.new_sign_bits(h.shape[0], w1.shape[0], h.device)
-    f = ops.gemm_nt(h, run.weights.fwd(w1), run.act, bias=b1, relu=True, sign_bits_out=bits)
-    y = ops.gemm_nt(f, run.weights.fwd(w2), out_dtype, bias=b2, dropout_p=run.p(p), rng_state=run.rng,
-                    site=site_ffn(layer), residual=x2d if residual else None)
+    f = linear_nt(run, h, w1, run.act, bias=b1, relu=True, sign_bits_out=bits)
+    y = linear_nt(run, f, w2, out_dtype, bias=b2, dropout_p=run.p(p), rng_state=run.rng,
+                  site=site_ffn(layer), residual=x2d if residual else None)
     return y, (x2d, h, mean, rstd, f, bits)
 
 
@@ -275,15 +319,15 @@ def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2:
         cs_part = None
         vector_rows = getattr(sink, "vector_rows", None)
         if bits is not None and vector_rows is not None:
-            rows = ops.gemm_nt_colsum_rows(run.act, g.shape[0], w1.shape[0], w2.shape[0])
+            rows = ops.gemm_nt_colsum_rows(run.act, g.shape[0], w1.shape[0], w2.shape[0], in_dtype=_op_dtype(run, w2.shape[0], grad=True))
             if rows:
                 cs_part = vector_rows(keys["b1"], w1.shape[0], rows)
         if cs_part is not None:
             # the b1 gradient (column sums of df) leaves the dX GEMM's epilogue as partial rows
-            df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], sign_bits=bits, colsum_part=cs_part)
+            df = linear_dx(run, g, w2, run.act, sign_bits=bits, colsum_part=cs_part)
         else:
             if bits is not None:
-                df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], sign_bits=bits)
+                df = linear_dx(run, g, w2, run.act, sign_bits=bits)
             else:
                 df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], relu_mask=f)
             part, stride, n = sink.vector(keys["b1"], w1.shape[0])
@@ -292,10 +336,10 @@ def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2:
     if not need_dx:
         return None
     if ln_w is not None:
-        dh = ops.gemm_nt(df, run.weights.bwd(w1), _dh_dtype(run, ln_w), K=w1.shape[0])
+        dh = linear_dx(run, df, w1, _dh_dtype(run, ln_w))
         dx, g_next = _ln_tail(run, dh, x2d, ln_w, mean, rstd, dy if residual else None, sink, keys, emit)
         return (dx, g_next) if emit is not None else dx
-    dx = ops.gemm_nt(df, run.weights.bwd(w1), torch.float32, K=w1.shape[0], residual=dy if residual else None)
+    dx = linear_dx(run, df, w1, torch.float32, residual=dy if residual else None)
     return (dx, None) if emit is not None else dx
 
 

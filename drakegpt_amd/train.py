@@ -130,7 +130,7 @@ def main(argv=None):
     ap.add_argument("--iters", type=int, default=TRAIN["iters"])
     ap.add_argument("--eval-interval", type=int, default=TRAIN["eval_interval"])
     ap.add_argument("--eval-iters", type=int, default=TRAIN["eval_iters"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--model-dir", default="model")
     ap.add_argument("--sample", type=int, default=100)
     args = ap.parse_args(argv)
