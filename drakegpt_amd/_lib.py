@@ -18,7 +18,7 @@ DG_F32 = 0
 DG_BF16 = 1
 DG_FP8_E4M3 = 2
 DG_FP8_E5M2 = 3
-ABI_VERSION = 5
+ABI_VERSION = 7
 
 
 class GemmNtArgs(C.Structure):
@@ -77,6 +77,7 @@ SIGNATURES = {
     "dg_gemm_nt_sign_bits_bytes": [_i, _i],
     "dg_fp8_amax": [_vp, _i, _i64, _vp, _i, _vp, _vp],
     "dg_fp8_quantize": [_vp, _i, _vp, _i, _i64, _vp, _i, _vp, _vp, _vp],
+    "dg_fp8_quantize_delayed": [_vp, _i, _vp, _i, _i64, _vp, _vp, _vp, _vp],
     "dg_gemm_tn": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp],
     "dg_gemm_tn_grouped": [C.POINTER(TnProblem), _i, _i, _vp, _i64, _vp],
     "dg_gemm_tn_grouped_workspace_bytes": [C.POINTER(TnProblem), _i],

@@ -151,6 +151,8 @@ class TrainEngine:
         self.dev = p0.device
         self.act = model.act_dtype
         self.fp8 = bool(getattr(model, "fp8", False))
+        self.fp8_sites: Dict[str, Tensor] = {}
+        self._fp8_seeded = False
         self.B = int(batch_size)
         self.T = int(context_length or model.context_length)
         if self.T > model.context_length:
@@ -392,7 +394,7 @@ class TrainEngine:
         if self.fp8:
             self.seg_f = torch.tensor(seg_f, dtype=torch.int64, device=dev)
             self.seg_b = torch.tensor(seg_b, dtype=torch.int64, device=dev)
-            self.w_amax = torch.zeros(len(seg_f), dtype=torch.float32, device=dev)
+            self.w_amax = torch.zeros(len(seg_f) * ops.FP8_AMAX_PARTS, dtype=torch.float32, device=dev)
 
     def refresh_shadows(self):
         """bf16 copy of the GEMM weights + every W^T.  Call after the weights change outside step()
@@ -496,11 +498,21 @@ class TrainEngine:
         self._backward_layers(st, reversed(range(self.L)))
         self._backward_end(st)
 
+    def _train_run(self) -> S.Run:
+        """per-step runtime configuration of the training program.  fp8: every quantisation site keeps its amax history in
+        self.fp8_sites (one-pass delayed scaling); the first execution (the eager warm-up before capture, or the first eager
+        step) quantises just in time and seeds the history"""
+        seed = self.fp8 and not self._fp8_seeded
+        if seed:
+            self._fp8_seeded = True
+        return S.Run(act=self.act, rng=self.state if self.p_drop > 0.0 else None, weights=self.weights, fp8=self.fp8,
+                     fp8_sites=self.fp8_sites if self.fp8 else None, fp8_seed=seed, step_word=self.state)
+
     def _prog_fwd_bwd(self):
         """gather the batch, forward, backward, reduce the gradient partials"""
         if self.corpus is not None:
             ops.batch_gather(self.corpus, self.offsets, self.T, self.x, self.y)
-        run = S.Run(act=self.act, rng=self.state if self.p_drop > 0.0 else None, weights=self.weights, fp8=self.fp8)
+        run = self._train_run()
         logits, rows, ctx = self._forward(run, self.x, self.y, True)
         if self.keep_logits:
             self.last_logits = logits
@@ -516,7 +528,7 @@ class TrainEngine:
         def first():
             if self.corpus is not None:
                 ops.batch_gather(self.corpus, self.offsets, self.T, self.x, self.y)
-            run = S.Run(act=self.act, rng=self.state if self.p_drop > 0.0 else None, weights=self.weights, fp8=self.fp8)
+            run = self._train_run()
             logits, rows, ctx = self._forward(run, self.x, self.y, True)
             if self.keep_logits:
                 self.last_logits = logits

@@ -19,6 +19,7 @@ Tensor = torch.Tensor
 
 _DT = {torch.float32: DG_F32, torch.bfloat16: DG_BF16, torch.float8_e4m3fn: DG_FP8_E4M3, torch.float8_e5m2: DG_FP8_E5M2}
 FP8_DTYPES = (torch.float8_e4m3fn, torch.float8_e5m2)
+FP8_AMAX_PARTS = 256            # DG_FP8_AMAX_PARTS
 
 
 def dt_code(dtype: torch.dtype) -> int:
@@ -279,11 +280,27 @@ def fp8_quantize(x: Tensor, fmt: torch.dtype, seg: Optional[Tensor] = None, n_se
     if scale_inv is None:
         scale_inv = torch.empty((ns,), dtype=torch.float32, device=x.device)
     if amax is None:
-        amax = torch.empty((ns,), dtype=torch.float32, device=x.device)
+        amax = torch.empty((ns * FP8_AMAX_PARTS,), dtype=torch.float32, device=x.device)      # partial maxima, reduced by the cast kernel
     n = x.numel()
     check(lib.dg_fp8_amax(_p(x), dt_code(x.dtype), n, _p(seg), ns, _p(amax), _stream()), "dg_fp8_amax")
     check(lib.dg_fp8_quantize(_p(x), dt_code(x.dtype), _p(out), dt_code(fmt), n, _p(seg), ns, _p(amax), _p(scale_inv), _stream()),
           "dg_fp8_quantize")
+    return out, scale_inv
+
+
+def fp8_quantize_delayed(x: Tensor, fmt: torch.dtype, parts2: Tensor, rng_state: Tensor):
+    """one-pass delayed scaling: scale from the amax this call site recorded one step ago (parts2 [2 * FP8_AMAX_PARTS] fp32, the
+    slot chosen by the device-side step word rng_state[2]); records this tensor's amax for the next step.
+    Returns (q, scale_inv [1])."""
+    _chk(x, "x")
+    _chk(parts2, "parts2", torch.float32)
+    _chk(rng_state, "rng_state", torch.int32)
+    if parts2.numel() != 2 * FP8_AMAX_PARTS:
+        raise RuntimeError("fp8_quantize_delayed: parts2 must hold 2 x FP8_AMAX_PARTS floats")
+    out = torch.empty(x.shape, dtype=fmt, device=x.device)
+    scale_inv = torch.empty((1,), dtype=torch.float32, device=x.device)
+    check(lib.dg_fp8_quantize_delayed(_p(x), dt_code(x.dtype), _p(out), dt_code(fmt), x.numel(), _p(parts2), _p(rng_state), _p(scale_inv),
+                                      _stream()), "dg_fp8_quantize_delayed")
     return out, scale_inv
 
 

@@ -161,6 +161,9 @@ class Run:
     rng: Optional[Tensor]            # device rng state snapshot; None => no dropout (eval)
     weights: object                  # OnTheFlyWeights | engine.ShadowWeights
     fp8: bool = False                # precision = "fp8": the block Linears (forward and dX) run on fp8 operands
+    fp8_sites: Optional[dict] = None # engine only: per call site [2 x FP8_AMAX_PARTS] amax history => one-pass delayed scaling
+    fp8_seed: bool = False           # engine warm-up: quantise just in time and seed the sites' history with this batch's amax
+    step_word: Optional[Tensor] = None   # device {seed, step} words: the step parity selects the history slot
 
     def p(self, p: float) -> float:
         return p if (self.rng is not None and p > 0.0) else 0.0
@@ -171,24 +174,40 @@ def fp8_k_ok(k: int) -> bool:
     return k % 128 == 0 and k >= 256
 
 
-def linear_nt(run: Run, x: Tensor, W: Tensor, out_dtype: torch.dtype, **epi) -> Tensor:
+def _quantize_operand(run: Run, x: Tensor, fmt: torch.dtype, site: Optional[str]):
+    """an activation / gradient operand as fp8.  Module path and evaluation: just in time (amax pass + cast pass).  Training
+    engine: the call site `site` keeps the amax of the previous step and the tensor is cast in one pass (delayed scaling);
+    the engine's eager warm-up step seeds that history with a just-in-time amax."""
+    if run.fp8_sites is None or site is None:
+        return ops.fp8_quantize(x, fmt)
+    parts2 = run.fp8_sites.get(site)
+    if run.fp8_seed or parts2 is None:
+        if parts2 is None:
+            parts2 = run.fp8_sites[site] = torch.zeros(2 * ops.FP8_AMAX_PARTS, dtype=torch.float32, device=x.device)
+        xq, xs = ops.fp8_quantize(x, fmt, amax=parts2[:ops.FP8_AMAX_PARTS])
+        parts2[ops.FP8_AMAX_PARTS:].copy_(parts2[:ops.FP8_AMAX_PARTS])
+        return xq, xs
+    return ops.fp8_quantize_delayed(x, fmt, parts2, run.step_word)
+
+
+def linear_nt(run: Run, x: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: Optional[str] = None, **epi) -> Tensor:
     """forward of a block Linear: epilogue(x W^T), x [M, in] in the activation dtype, W [out, in] the fp32 master.
-    fp8 mode: x is quantised to e4m3 just in time (amax pass + cast pass), W comes as its persistent e4m3 shadow."""
+    fp8 mode: x is quantised to e4m3 (see _quantize_operand), W comes as its persistent e4m3 shadow."""
     if run.fp8 and fp8_k_ok(W.shape[1]) and x.is_contiguous() and x.dtype == torch.bfloat16:
         wq, ws = run.weights.fwd8(W)
-        xq, xs = ops.fp8_quantize(x, E4M3)
+        xq, xs = _quantize_operand(run, x, E4M3, fp8_site)
         return ops.gemm_nt(xq, wq, out_dtype, scale_a=xs, scale_b=ws, **epi)
     return ops.gemm_nt(x, run.weights.fwd(W), out_dtype, **epi)
 
 
-def linear_dx(run: Run, g: Tensor, W: Tensor, out_dtype: torch.dtype, **epi) -> Tensor:
+def linear_dx(run: Run, g: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: Optional[str] = None, **epi) -> Tensor:
     """dX of a block Linear: epilogue(g W), g [M, out] in the activation dtype (a gradient: e5m2 in fp8 mode), W^T shadow
     [in, out padded]"""
     K = W.shape[0]
     if run.fp8 and fp8_k_ok(K) and g.is_contiguous() and g.dtype == torch.bfloat16 and g.shape[1] == K:
         wq, ws = run.weights.bwd8(W)
         if wq.shape[1] == K:
-            gq, gs = ops.fp8_quantize(g, E5M2)
+            gq, gs = _quantize_operand(run, g, E5M2, fp8_site)
             return ops.gemm_nt(gq, wq, out_dtype, K=K, scale_a=gs, scale_b=ws, **epi)
     return ops.gemm_nt(g, run.weights.bwd(W), out_dtype, K=K, **epi)
 
@@ -233,10 +252,10 @@ def attn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tenso
         h, mean, rstd = ops.layernorm_fwd(x2d, ln_w, ln_b, run.act)
     else:
         h, mean, rstd = _as_act(run, x2d), None, None
-    qkv = linear_nt(run, h, wqkv, run.act)
+    qkv = linear_nt(run, h, wqkv, run.act, fp8_site=f"{layer}.h1")
     o, lse = ops.attn_fwd(qkv, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer))
     if wproj is not None:
-        y = linear_nt(run, o, wproj, torch.float32, bias=bproj, dropout_p=run.p(p_proj),
+        y = linear_nt(run, o, wproj, torch.float32, fp8_site=f"{layer}.o", bias=bproj, dropout_p=run.p(p_proj),
                       rng_state=run.rng, site=site_proj(layer), residual=x2d if residual else None)
     else:
         if residual:
@@ -260,7 +279,7 @@ def attn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], wqkv: Tensor, 
             g = ops.dropout_bwd_cast(dy, run.act, run.p(p_proj), run.rng, site_proj(layer), colsum_part=part,
                                      part_stride=stride, n_partials=n)
         weight_grad(sink, keys["wproj"], g, o, wproj.shape[0], wproj.shape[1])
-        do = linear_dx(run, g, wproj, run.act)
+        do = linear_dx(run, g, wproj, run.act, fp8_site=f"{layer}.g_proj")
     else:
         do = _as_act(run, dy)
     dqkv = ops.attn_bwd(qkv, o, do, lse, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer))
@@ -268,10 +287,10 @@ def attn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], wqkv: Tensor, 
     if not need_dx:
         return None
     if ln_w is not None:
-        dh = linear_dx(run, dqkv, wqkv, _dh_dtype(run, ln_w))
+        dh = linear_dx(run, dqkv, wqkv, _dh_dtype(run, ln_w), fp8_site=f"{layer}.dqkv")
         dx, g_next = _ln_tail(run, dh, x2d, ln_w, mean, rstd, dy if residual else None, sink, keys, emit)
         return (dx, g_next) if emit is not None else dx
-    dx = linear_dx(run, dqkv, wqkv, torch.float32, residual=dy if residual else None)
+    dx = linear_dx(run, dqkv, wqkv, torch.float32, fp8_site=f"{layer}.dqkv", residual=dy if residual else None)
     return (dx, None) if emit is not None else dx
 
 
@@ -295,8 +314,8 @@ def ffn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor
     if (ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w1.shape[1], in_dtype=_op_dtype(run, w1.shape[1]))
             and ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w2.shape[0], in_dtype=_op_dtype(run, w2.shape[0], grad=True))):
         bits = ops.new_sign_bits(h.shape[0], w1.shape[0], h.device)
-    f = linear_nt(run, h, w1, run.act, bias=b1, relu=True, sign_bits_out=bits)
-    y = linear_nt(run, f, w2, out_dtype, bias=b2, dropout_p=run.p(p), rng_state=run.rng,
+    f = linear_nt(run, h, w1, run.act, fp8_site=f"{layer}.h2", bias=b1, relu=True, sign_bits_out=bits)
+    y = linear_nt(run, f, w2, out_dtype, fp8_site=f"{layer}.f", bias=b2, dropout_p=run.p(p), rng_state=run.rng,
                   site=site_ffn(layer), residual=x2d if residual else None)
     return y, (x2d, h, mean, rstd, f, bits)
 
@@ -324,10 +343,10 @@ def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2:
                 cs_part = vector_rows(keys["b1"], w1.shape[0], rows)
         if cs_part is not None:
             # the b1 gradient (column sums of df) leaves the dX GEMM's epilogue as partial rows
-            df = linear_dx(run, g, w2, run.act, sign_bits=bits, colsum_part=cs_part)
+            df = linear_dx(run, g, w2, run.act, fp8_site=f"{layer}.g_ffn", sign_bits=bits, colsum_part=cs_part)
         else:
             if bits is not None:
-                df = linear_dx(run, g, w2, run.act, sign_bits=bits)
+                df = linear_dx(run, g, w2, run.act, fp8_site=f"{layer}.g_ffn", sign_bits=bits)
             else:
                 df = ops.gemm_nt(g, run.weights.bwd(w2), run.act, K=w2.shape[0], relu_mask=f)
             part, stride, n = sink.vector(keys["b1"], w1.shape[0])
@@ -336,10 +355,10 @@ def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2:
     if not need_dx:
         return None
     if ln_w is not None:
-        dh = linear_dx(run, df, w1, _dh_dtype(run, ln_w))
+        dh = linear_dx(run, df, w1, _dh_dtype(run, ln_w), fp8_site=f"{layer}.df")
         dx, g_next = _ln_tail(run, dh, x2d, ln_w, mean, rstd, dy if residual else None, sink, keys, emit)
         return (dx, g_next) if emit is not None else dx
-    dx = linear_dx(run, df, w1, torch.float32, residual=dy if residual else None)
+    dx = linear_dx(run, df, w1, torch.float32, fp8_site=f"{layer}.df", residual=dy if residual else None)
     return (dx, None) if emit is not None else dx
 
 

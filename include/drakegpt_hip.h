@@ -44,7 +44,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 5   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 7   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -158,13 +158,23 @@ int dg_gemm_nt_colsum_rows(const dg_gemm_nt_args* args);
 int64_t dg_gemm_nt_sign_bits_bytes(int M, int N);
 
 /* fp8 operand preparation (per-tensor scaling, just in time) for dg_gemm_nt's fp8 form -- precision = "fp8".
- * dg_fp8_amax: amax[s] = max |x| over segment s of the flat buffer x (n elements).  seg = NULL: one segment; else a device table
- * of n_seg x 2 int64 {first element, element count}, both multiples of 8 (all weight matrices of the step in one launch).
+ * dg_fp8_amax: DG_FP8_AMAX_PARTS partial maxima of |x| per segment of the flat buffer x (n elements) into amax_parts
+ * [n_seg * DG_FP8_AMAX_PARTS] (no atomics, nothing to zero).  seg = NULL: one segment; else a device table of n_seg x 2 int64
+ * {first element, element count}, both multiples of 8 (all weight matrices of the step in one launch).
  * dg_fp8_quantize: q[i] = fp8(clamp(x[i] * FMAX / amax[s])) in format fmt (DG_FP8_E4M3 / DG_FP8_E5M2), one byte per element,
- * and scale_inv[s] = amax[s] / FMAX (1 when amax is 0), the factor dg_gemm_nt multiplies back.  n % 8 == 0. */
-int dg_fp8_amax(const void* x, int dtype, int64_t n, const int64_t* seg, int n_seg, float* amax, void* stream);
+ * with amax[s] = the maximum of segment s's partial maxima, and scale_inv[s] = amax[s] / FMAX (1 when amax is 0), the factor
+ * dg_gemm_nt multiplies back.  n % 8 == 0. */
+#define DG_FP8_AMAX_PARTS 256
+int dg_fp8_amax(const void* x, int dtype, int64_t n, const int64_t* seg, int n_seg, float* amax_parts, void* stream);
 int dg_fp8_quantize(const void* x, int dtype, void* q, int fmt, int64_t n, const int64_t* seg, int n_seg,
-                    const float* amax, float* scale_inv, void* stream);
+                    const float* amax_parts, float* scale_inv, void* stream);
+/* Delayed scaling in ONE pass (the training engine's activations and gradients: the amax pass is what made just-in-time
+ * scaling slower than the bf16 GEMMs it replaced): q = fp8(clamp(x * FMAX / amax_prev)), amax_prev = what this call site
+ * recorded one step ago, and this tensor's own partial maxima are recorded for the next step.  parts2: [2][DG_FP8_AMAX_PARTS]
+ * floats owned by the call site; slot (rng_state[2] & 1) is written, the other one read (rng_state[2] is the step word that
+ * dg_state_advance increments).  Seed both slots with dg_fp8_amax before the first use.  scale_inv[0] = amax_prev / FMAX. */
+int dg_fp8_quantize_delayed(const void* x, int dtype, void* q, int fmt, int64_t n, float* parts2,
+                            const uint32_t* rng_state, float* scale_inv, void* stream);
 
 /* GEMM "TN": weight gradients, dW[P,Q] = sum_r A[r,P] * B[r,Q]  (A = dY [R,P], B = X [R,Q]).
  * The contraction over the R = B*T rows is split n_splits ways across workgroups; split s

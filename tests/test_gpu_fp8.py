@@ -216,8 +216,10 @@ def test_fp8_engine_step_against_bf16_engine_and_oracle(dev):
         per = {k: rel(out["fp8"][3][k], gr[k]) for k in keys}
         print("[parity] fp8 worst tensors vs reference: " + str(sorted(per.items(), key=lambda kv: -kv[1])[:4]), flush=True)
     assert e["bf16"][1] < 6e-3 and e["bf16"][2] < 2e-2
-    assert e["fp8"][0] < 5e-3 and e["fp8"][1] < 8e-2 and e["fp8"][2] < 0.35, e
-    assert e["fp8_vs_bf16"][1] < 8e-2 and e["fp8_vs_bf16"][2] < 0.35, e
+    # measured (round 2): fp8 vs the reference arithmetic: loss 6.5e-5, logits 2.3e-2, flat gradient 6.1e-2 (worst tensors, the
+    # LayerNorm-2 gains and W1: 0.18); bf16 on the same step: 1.1e-5, 2.8e-3, 1.3e-2
+    assert e["fp8"][0] < 1e-3 and e["fp8"][1] < 5e-2 and e["fp8"][2] < 0.12, e
+    assert e["fp8_vs_bf16"][1] < 5e-2 and e["fp8_vs_bf16"][2] < 0.12, e
 
 
 def test_fp8_module_path_equals_engine(dev):
@@ -266,3 +268,30 @@ def test_fp8_training_tracks_bf16(dev):
         final[prec] = (ls[0], sum(ls[-5:]) / 5)
     assert final["bf16"][1] < 0.6 * final["bf16"][0] and final["fp8"][1] < 0.6 * final["fp8"][0], final
     assert abs(final["fp8"][1] - final["bf16"][1]) < 0.03 * final["bf16"][1], final
+
+
+def test_fp8_quantize_delayed_uses_last_steps_amax(dev):
+    """one-pass delayed scaling: the scale comes from the slot the previous step wrote (step parity from the device-side step
+    word), this tensor's amax goes to the other slot; values beyond last step's range saturate instead of overflowing"""
+    from drakegpt_amd import ops
+    P = ops.FP8_AMAX_PARTS
+    g = torch.Generator().manual_seed(9)
+    x1 = (torch.randn(512, 1024, generator=g) * 0.7).bfloat16()
+    x2 = (torch.randn(512, 1024, generator=g) * 1.9).bfloat16()
+    state = ops.new_rng_state(1, dev, 6)                           # step 6: writes slot 0, reads slot 1
+    parts2 = torch.zeros(2 * P, device=dev)
+    _, _ = ops.fp8_quantize(x1.to(dev), E4, amax=parts2[P:])       # seed slot 1 with amax(x1), as the engine's warm-up does
+    q, sinv = ops.fp8_quantize_delayed(x2.to(dev), E4, parts2, state)
+    torch.cuda.synchronize()
+    a1, a2 = x1.float().abs().max(), x2.float().abs().max()
+    scale = torch.tensor(448.0) / a1
+    want = (x2.float() * scale).clamp(-448, 448).to(E4)
+    assert torch.equal(q.cpu().view(torch.uint8), want.view(torch.uint8))
+    assert (q.cpu().float().abs() == 448).sum() > 0                # x2 outgrew x1's range: clipped, finite
+    assert abs(sinv.item() * scale.item() - 1.0) < 1e-6
+    assert parts2[:P].max().item() == a2.item() and parts2[P:].max().item() == a1.item()
+    ops.state_advance(state)                                       # step 7: reads slot 0 (amax of x2), writes slot 1
+    q3, s3 = ops.fp8_quantize_delayed(x1.to(dev), E5, parts2, state)
+    want3 = (x1.float() * (torch.tensor(57344.0) / a2)).clamp(-57344, 57344).to(E5)
+    assert torch.equal(q3.cpu().view(torch.uint8), want3.view(torch.uint8))
+    assert parts2[P:].max().item() == a1.item() and abs(s3.item() * (57344.0 / a2.item()) - 1.0) < 1e-6
