@@ -763,7 +763,15 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped_kernel(TnGroup gp) {
 // [64 r][128 cols] images (A columns 0..127, A columns 128..255, B) = 48 KB, three stages.
 #define TN2_STAGE 49152
 #define TN2_NST 3
-__global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
+// WT (wave tile): 0 = 8 MFMA waves of 64 x 64 (4 x 2), two per SIMD, each reading a whole stage and then issuing its 32 MFMAs:
+// 256 transposed reads per K step and CU against 1024 MFMA cycles -- read-bound.  1 = 4 MFMA waves of 128 x 64 (2 x 2), one per
+// SIMD: 8 + 4 fragments per 32 MFMAs = 192 transposed reads per K step and CU (three quarters), and since a lone wave per SIMD
+// has nobody to overlap with, the reads of the next K half are in flight while the MFMAs of the current one run (the NT
+// kernel's barrier-in-the-middle loop).  128 accumulator + 96 fragment registers: 2 waves per SIMD (MFMA + loader) at <= 256.
+template <int WT>
+__global__ __launch_bounds__(WT ? 512 : 768) void gemm_tn_grouped256_kernel(TnGroup gp) {
+    constexpr int NMW = WT ? 4 : 8;                // MFMA waves
+    constexpr int NI = WT ? 8 : 4;                 // 16-row fragments of A per wave
     __shared__ __attribute__((aligned(16))) char lds[TN2_NST * TN2_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
     const int G = gridDim.x;
@@ -818,9 +826,9 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
     }
     if (total == 0) return;
 
-    if (wave >= 8) {
+    if (wave >= NMW) {
         // ---- loader role: 48 pieces of 1 KB (4 rows x 256 B) per stage, 12 per wave: pieces 0-15 -> image A0, 16-31 -> A1, 32-47 -> B
-        const int lw = wave - 8;
+        const int lw = wave - NMW;
         const int prow = lane >> 4, slot = lane & 15;
         const char* src[12];
         int64_t step[12];
@@ -872,24 +880,25 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
     }
 
     // ---- MFMA role
-    const int wp = wave >> 1, wq = wave & 1;
-    f32x4 acc[4][4];
+    const int wp = wave >> 1, wq = wave & 1;       // WT 0: wp 0..3 (64 rows each), WT 1: wp 0..1 (128 rows = one A image each)
+    constexpr int WROWS = WT ? 128 : 64;
+    f32x4 acc[NI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
-    const int aimg = (wp >> 1) * 16384, acol = (wp & 1) * 64;
-    auto read_frags = [&](u32x4 (&fa)[4], u32x4 (&fb)[4], const char* buf, int ks) {
+    const int aimg = WT ? wp * 16384 : (wp >> 1) * 16384, acol = WT ? 0 : (wp & 1) * 64;
+    auto read_frags = [&](u32x4 (&fa)[NI], u32x4 (&fb)[4], const char* buf, int ks) {
         const int r0 = ks * 32 + fg * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = tn_frag_bf16(buf + aimg, r0, acol + i * 16, lane);
+        for (int i = 0; i < NI; ++i) fa[i] = tn_frag_bf16(buf + aimg, r0, acol + i * 16, lane);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = tn_frag_bf16(buf + 32768, r0, wq * 64 + j * 16, lane);
     };
-    auto mma_all = [&](const u32x4 (&fa)[4], const u32x4 (&fb)[4]) {
+    auto mma_all = [&](const u32x4 (&fa)[NI], const u32x4 (&fb)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb[j], fa[i], acc[i][j]);
     };
@@ -902,15 +911,16 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
     auto store_tile = [&]() {
         const TnProblem& pr = gp.pr[cx.pi];
         if (cx.half != 2) {
-            float* part = (float*)(gp.ws + ((size_t)cx.tile * 8 + wave) * 16384);
+            // per wave NI x 4 accumulators of 1 KB (64 lanes x 16 B): 16 KB (WT 0) or 32 KB (WT 1: two of the tile's eight slots)
+            float* part = (float*)(gp.ws + ((size_t)cx.tile * 8 + wave * (8 / NMW)) * 16384);
             unsigned* flag = (unsigned*)(gp.ws + (size_t)gp.total_tiles * 8 * 16384) + cx.tile * 8 + wave;
-            // The 16 KB of a wave move as 16 x (64 lanes x 16 B) with the sc0 sc1 cache bits: system-scope write-through
+            // The partials move as (64 lanes x 16 B) pieces with the sc0 sc1 cache bits: system-scope write-through
             // stores and L2-bypassing loads, i.e. coherent between XCDs without any cache-wide maintenance.  (One relaxed
             // agent-scope atomic per float -- the portable spelling -- cost ~30 us per hand-over.)
             char* pw = (char*)part + lane * 16;
             if (cx.half == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(pw + (i * 4 + j) * 1024), "v"(acc[i][j]) : "memory");
@@ -926,10 +936,19 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
                                "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]),
                                "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3])
                              :: "memory");
+                if constexpr (WT != 0) {
+                    // (the other sixteen: an asm statement takes at most 30 operands; volatile statements keep their order, so
+                    // these registers stay live and untouched through the wait above)
+                    asm volatile(""
+                                 : "+v"(acc[4][0]), "+v"(acc[4][1]), "+v"(acc[4][2]), "+v"(acc[4][3]), "+v"(acc[5][0]), "+v"(acc[5][1]),
+                                   "+v"(acc[5][2]), "+v"(acc[5][3]), "+v"(acc[6][0]), "+v"(acc[6][1]), "+v"(acc[6][2]), "+v"(acc[6][3]),
+                                   "+v"(acc[NI - 1][0]), "+v"(acc[NI - 1][1]), "+v"(acc[NI - 1][2]), "+v"(acc[NI - 1][3])
+                                 :: "memory");
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 return;
@@ -942,26 +961,26 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
                 __builtin_amdgcn_s_sleep(8);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            f32x4 t[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(t[k]) : "v"(pw + k * 1024) : "memory");
-            // one wait for all sixteen; the values pass through it so that nothing reads them earlier
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
-                           "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15])
-                         :: "memory");
+            for (int c = 0; c < NI / 2; ++c) {                 // eight 1 KB pieces at a time (32 registers)
+                f32x4 t[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int k = 0; k < 8; ++k) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(t[k]) : "v"(pw + (c * 8 + k) * 1024) : "memory");
+                // one wait for all eight; the values pass through it so that nothing reads them earlier
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])
+                             :: "memory");
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += t[i * 4 + j];
+                for (int k = 0; k < 8; ++k) acc[2 * c + (k >> 2)][k & 3] += t[k];
+            }
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
         float* out = pr.out;
         const bool vec = (pr.ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = cx.p0 + wp * 64 + i * 16 + fr;
+        for (int i = 0; i < NI; ++i) {
+            const int row = cx.p0 + wp * WROWS + i * 16 + fr;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int col = cx.q0 + wq * 64 + j * 16 + 4 * fg;
@@ -978,24 +997,99 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped256_kernel(TnGroup gp) {
             }
         }
     };
-    u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
+    u32x4 fa0[NI], fb0[4], fa1[NI], fb1[4];
     __builtin_amdgcn_s_barrier();                                  // stage 0 published by the loaders
     int kt = 0, buf_i = 0;
-    for (int g = 0; g < total; ++g) {
-        const char* buf = lds + buf_i * TN2_STAGE;
-        read_frags(fa0, fb0, buf, 0);
-        read_frags(fa1, fb1, buf, 1);
-        mma_all(fa0, fb0);
-        mma_all(fa1, fb1);
-        if (++buf_i == TN2_NST) buf_i = 0;
-        if (++kt == cx.kb - cx.ka) {
-            store_tile();
-            kt = 0;
-            next_item();
+    if constexpr (WT != 0) {
+        // One MFMA wave per SIMD, nobody to overlap with: while the 32 MFMAs of a K half run, the fragments of the NEXT half are
+        // requested -- row fragment i right after its four MFMAs have been issued, into the registers they free (A: 8 live
+        // fragments instead of 16), the 4 column fragments up front.  The next stage's first half sits behind the barrier
+        // that publishes it.
+        // Fragment addresses by hand (tn_frag_bf16's arithmetic, factored): the two transposed reads of fragment I (16 columns
+        // at 16 I of a 128-column image) at K half ks of the stage at byte offset sb are
+        //     sb + img + 8192 ks + ((P0 | P1) ^ (I << 5)),   P = lane part with the swizzle's lane bits folded in,
+        // i.e. ONE v_xor with a literal per read on top of two per-lane registers per operand -- the generic form kept ~50
+        // hoisted address registers alive and pushed the kernel over its 256-register budget (690 spilled dwords).
+        typedef __attribute__((address_space(3))) char lds_char;
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        lds_char* const lbase = (lds_char*)lds;
+        const int q4 = (lane & 15) >> 2, pp = lane & 3, b0 = pp >> 1;
+        const int mswz = ((q4 << 1) | (fg & 1)) << 5;
+        const int P0 = (2048 * fg + 256 * q4 + 16 * b0 + 8 * (pp & 1)) ^ mswz;
+        const int P1 = (2048 * fg + 256 * q4 + 1024 + 16 * (b0 ^ 1) + 8 * (pp & 1)) ^ mswz;
+        const int PA0 = P0 + wp * 16384, PA1 = P1 + wp * 16384;                    // A image of this wave row
+        const int PB0 = (P0 ^ (wq << 7)) + 32768, PB1 = (P1 ^ (wq << 7)) + 32768;  // B image, fragments 4 wq + j
+        auto frag2 = [&](int a0, int a1) -> u32x4 {
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lbase + a0));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lbase + a1));
+            return __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        // (the four stage bases pass through an empty asm once per K half: opaque to the optimiser, which otherwise hoists all
+        // 48 xor results out of the loop again and spills them)
+        int sa0, sa1, sb0, sb1;
+        auto stage_bases = [&](int sb) {
+            sa0 = PA0 + sb; sa1 = PA1 + sb; sb0 = PB0 + sb; sb1 = PB1 + sb;
+            asm volatile("" : "+v"(sa0), "+v"(sa1), "+v"(sb0), "+v"(sb1));
+        };
+        auto read_a = [&](u32x4& f, int ks, int i) { f = frag2((sa0 ^ (i << 5)) + 8192 * ks, (sa1 ^ (i << 5)) + 8192 * ks); };
+        auto read_b = [&](u32x4 (&fb)[4], int ks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = frag2((sb0 ^ (j << 5)) + 8192 * ks, (sb1 ^ (j << 5)) + 8192 * ks);
+        };
+        // fb0 / fb1: column fragments of the two K halves; fa0: row fragments of the half in progress, refilled in place
+        stage_bases(0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) read_a(fa0[i], 0, i);
+        read_b(fb0, 0);
+        for (int g = 0; g < total; ++g) {
+            stage_bases(buf_i * TN2_STAGE);
+            if (++buf_i == TN2_NST) buf_i = 0;
+            read_b(fb1, 1);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb0[j], fa0[i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);         // the refill below reuses fragment i's registers: keep it behind its MFMAs
+                read_a(fa0[i], 1, i);
+            }
+            if (g + 1 < total) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // every read of stage g has returned: the loaders refill its buffer
+                __builtin_amdgcn_s_barrier();
+            }
+            // (after the last stage these reads fetch stale LDS contents that nobody uses: unconditional, so that the eight
+            // refills stay straight-line code between the MFMAs)
+            stage_bases(buf_i * TN2_STAGE);
+            read_b(fb0, 0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16<bf16_t>(fb1[j], fa0[i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                read_a(fa0[i], 0, i);
+            }
+            if (++kt == cx.kb - cx.ka) {
+                store_tile();
+                kt = 0;
+                next_item();
+            }
         }
-        if (g + 1 < total) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every read of stage g has returned: the loaders refill its buffer
-            __builtin_amdgcn_s_barrier();
+    } else {
+        for (int g = 0; g < total; ++g) {
+            const char* buf = lds + buf_i * TN2_STAGE;
+            read_frags(fa0, fb0, buf, 0);
+            read_frags(fa1, fb1, buf, 1);
+            mma_all(fa0, fb0);
+            mma_all(fa1, fb1);
+            if (++buf_i == TN2_NST) buf_i = 0;
+            if (++kt == cx.kb - cx.ka) {
+                store_tile();
+                kt = 0;
+                next_item();
+            }
+            if (g + 1 < total) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every read of stage g has returned: the loaders refill its buffer
+                __builtin_amdgcn_s_barrier();
+            }
         }
     }
 }
@@ -1200,7 +1294,9 @@ extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtyp
         }
         const int items = gp.splits == 3 ? tiles : gp.splits * gp.tiles_pad;
         const int grid = items < ncu ? items : ncu;
-        if (tile_p == 256) hipLaunchKernelGGL(gemm_tn_grouped256_kernel, dim3(grid), dim3(768), 0, s, gp);
+        static const int wt_mode = [] { const char* e = getenv("DG_TN_WAVETILE"); return e ? atoi(e) : 1; }();   // 0 = 8 waves of 64 x 64 (A/B runs)
+        if (tile_p == 256 && wt_mode) hipLaunchKernelGGL(gemm_tn_grouped256_kernel<1>, dim3(grid), dim3(512), 0, s, gp);
+        else if (tile_p == 256) hipLaunchKernelGGL(gemm_tn_grouped256_kernel<0>, dim3(grid), dim3(768), 0, s, gp);
         else hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(tiles < ncu ? tiles : ncu), dim3(768), 0, s, gp);
         DG_LAUNCH_CHECK();
     }
