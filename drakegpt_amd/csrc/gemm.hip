@@ -767,7 +767,12 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped_kernel(TnGroup gp) {
 // 256 transposed reads per K step and CU against 1024 MFMA cycles -- read-bound.  1 = 4 MFMA waves of 128 x 64 (2 x 2), one per
 // SIMD: 8 + 4 fragments per 32 MFMAs = 192 transposed reads per K step and CU (three quarters), and since a lone wave per SIMD
 // has nobody to overlap with, the reads of the next K half are in flight while the MFMAs of the current one run (the NT
-// kernel's barrier-in-the-middle loop).  128 accumulator + 96 fragment registers: 2 waves per SIMD (MFMA + loader) at <= 256.
+// kernel's barrier-in-the-middle loop, row fragments refilled in place).  MEASURED (round 2, same box, DG_TN_WAVETILE=1 vs 0):
+// 857 us vs 470 us -- 1.8x slower.  With the loader waves the kernel has 2 waves per SIMD, i.e. 256 registers per lane; 128
+// accumulators + 64 fragments fit on paper, but the allocator rotates the accumulators through the loop and reloads three
+// 16-byte values from scratch per K half, each a memory round trip in front of an MFMA that a single wave per SIMD cannot
+// hide.  Kept as an A/B variant; the default stays WT 0.  (The default is also closer to its HBM bound than to its LDS bound:
+// 1.87 GB in 455 us = 4.1 TB/s of the ~5.2 TB/s the chip sustains.)
 template <int WT>
 __global__ __launch_bounds__(WT ? 512 : 768) void gemm_tn_grouped256_kernel(TnGroup gp) {
     constexpr int NMW = WT ? 4 : 8;                // MFMA waves
@@ -1294,7 +1299,7 @@ extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtyp
         }
         const int items = gp.splits == 3 ? tiles : gp.splits * gp.tiles_pad;
         const int grid = items < ncu ? items : ncu;
-        static const int wt_mode = [] { const char* e = getenv("DG_TN_WAVETILE"); return e ? atoi(e) : 1; }();   // 0 = 8 waves of 64 x 64 (A/B runs)
+        static const int wt_mode = [] { const char* e = getenv("DG_TN_WAVETILE"); return e ? atoi(e) : 0; }();   // 1 = 4 MFMA waves of 128 x 64 (measured 1.8x SLOWER: see the kernel's WT note)
         if (tile_p == 256 && wt_mode) hipLaunchKernelGGL(gemm_tn_grouped256_kernel<1>, dim3(grid), dim3(512), 0, s, gp);
         else if (tile_p == 256) hipLaunchKernelGGL(gemm_tn_grouped256_kernel<0>, dim3(grid), dim3(768), 0, s, gp);
         else hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(tiles < ncu ? tiles : ncu), dim3(768), 0, s, gp);

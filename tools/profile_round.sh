@@ -3,7 +3,7 @@
 set -e
 TAG=$1
 R=$PWD; cd /tmp; export TMPDIR=/tmp; cd $R
-B="python bench.py --no-cpu-baseline --no-kernel-timing"
+B="python bench.py --no-cpu-baseline --no-kernel-timing --no-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- $B --steps 10 --warmup 3 > gpurun_out/prof_$TAG.log 2>&1
 cp gpurun_out/prof_$TAG/*/*_kernel_stats.csv gpurun_out/${TAG}_kernel_stats.csv
 python tools/step_trace.py gpurun_out/prof_$TAG/*/*_kernel_trace.csv --seq > gpurun_out/${TAG}_step_sequence.txt
