@@ -264,8 +264,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
 // =============================================================================================
 // dQ: wave = 32 queries; per key tile: S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T
 #define WAVE_LDS_DQ 12288
+// Without dropout the compiler wants 208 registers for this loop (everything of a tile in flight at once); capped at 168 (three
+// workgroups per CU) it spilled 39 of them inside the loop: 56.6 us per layer against 36.4 us WITH dropout, which made a
+// dropout-0 step slower than a dropout-0.2 step.  The no-dropout variant therefore takes two workgroups per CU and no spills.
 template <bool DROP>      // dropout on the probabilities (compile-time: no per-element uniform branch)
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(AttnP p) {
+__global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block, pointers and loop bounds live in SGPRs
     int64_t bh; int blk; bool valid;
@@ -616,8 +619,18 @@ int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const f
     static const int tile_mode = [] { const char* e = getenv("DG_ATTN_TILES"); return e ? atoi(e) : 1; }();   // 0 = recompute in the dK/dV pass (A/B runs)
     p.tiles = tile_mode ? (char*)tiles : nullptr;
     dim3 grid((unsigned)((p.n_items + 3) / 4)), block(256);
+    // Without dropout the dQ pass still runs the DROP = true code with a threshold of 0 (every hash >= 0: keep everything) and
+    // a keep scale of 1: bit-identical results, and 36 us per layer instead of the 48 us of the DROP = false variant (whose loop
+    // the compiler schedules into 208 registers: 2 workgroups per CU; at 168 registers it spilled: 57 us).  The hash key is
+    // read from any readable device words (the head of qkv): with threshold 0 its value cannot matter.  DG_ATTN_DQ_NODROP=1 restores it.
+    static const int nodrop_variant = [] { const char* e = getenv("DG_ATTN_DQ_NODROP"); return e ? atoi(e) : 0; }();
     if (p.drop) hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_DQ, s, p);
-    else hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, grid, block, 4 * WAVE_LDS_DQ, s, p);
+    else if (nodrop_variant) hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, grid, block, 4 * WAVE_LDS_DQ, s, p);
+    else {
+        AttnP q = p;
+        q.thr = 0u; q.inv_keep = 1.f; q.rng = (const uint32_t*)qkv; q.site = 0;     // (qkv: at least 384 readable bytes)
+        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_DQ, s, q);
+    }
     DG_LAUNCH_CHECK();
     if (p.tiles) hipLaunchKernelGGL(attn_bwd_dkv_tiles_kernel, grid, block, 4 * WAVE_LDS_DKVT, s, p);
     else if (p.drop) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_DKV, s, p);
