@@ -415,7 +415,8 @@ class TrainEngine:
             n = self.seg_f.shape[0]
             ops.fp8_quantize(self.shadow[self.offA:self.offA + self.layA.size], S.E4M3, seg=self.seg_f, n_seg=n, out=self.shadow8,
                              scale_inv=self.wscale_f, amax=self.w_amax)
-            ops.fp8_quantize(self.wt_flat, S.E4M3, seg=self.seg_b, n_seg=n, out=self.wt8_flat, scale_inv=self.wscale_b, amax=self.w_amax)
+            ops.fp8_quantize(self.wt_flat, S.E4M3, seg=self.seg_b, n_seg=n, out=self.wt8_flat, scale_inv=self.wscale_b, amax=self.w_amax,
+                             reuse_amax=True)          # W^T holds W's values: same per-matrix maxima, no second amax pass
 
     # -------------------------------------------------------------------------------- programs
     def _layer_params(self, l: int):

@@ -265,7 +265,7 @@ def gemm_nt_colsum_rows(dtype: torch.dtype, M: int, N: int, K: int, in_dtype: Op
 
 
 def fp8_quantize(x: Tensor, fmt: torch.dtype, seg: Optional[Tensor] = None, n_seg: int = 0, out: Optional[Tensor] = None,
-                 scale_inv: Optional[Tensor] = None, amax: Optional[Tensor] = None):
+                 scale_inv: Optional[Tensor] = None, amax: Optional[Tensor] = None, reuse_amax: bool = False):
     """per-tensor (per-segment) just-in-time scaling: q = fp8(x * FMAX / amax(x)) and the dequantisation factor amax / FMAX.
     x: contiguous bf16 / fp32, numel % 8 == 0.  seg: int64 device table [n_seg, 2] {first element, count} over x.view(-1)
     (all weight matrices of a step in two launches).  Returns (q with x's shape and dtype `fmt`, scale_inv [n_seg or 1])."""
@@ -282,7 +282,8 @@ def fp8_quantize(x: Tensor, fmt: torch.dtype, seg: Optional[Tensor] = None, n_se
     if amax is None:
         amax = torch.empty((ns * FP8_AMAX_PARTS,), dtype=torch.float32, device=x.device)      # partial maxima, reduced by the cast kernel
     n = x.numel()
-    check(lib.dg_fp8_amax(_p(x), dt_code(x.dtype), n, _p(seg), ns, _p(amax), _stream()), "dg_fp8_amax")
+    if not reuse_amax:          # reuse_amax: `amax` already holds the partial maxima of the same values (W^T after W)
+        check(lib.dg_fp8_amax(_p(x), dt_code(x.dtype), n, _p(seg), ns, _p(amax), _stream()), "dg_fp8_amax")
     check(lib.dg_fp8_quantize(_p(x), dt_code(x.dtype), _p(out), dt_code(fmt), n, _p(seg), ns, _p(amax), _p(scale_inv), _stream()),
           "dg_fp8_quantize")
     return out, scale_inv
