@@ -262,6 +262,164 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
 }
 
 // =============================================================================================
+// Forward, shared-tile form (T % 128 == 0, the balanced item order): the four waves of a workgroup own four query blocks of ONE
+// (batch, head), so they all walk the same key tiles -- in the kernel above every wave stages its own copy in private LDS and
+// runs its own dependent chain of up to nblk 32-key tiles: the launch takes as long as the longest wave (8 tiles x ~2 500 cycles
+// at T = 256) while the SIMDs are busy a third of that time.  Here
+//   * a key tile is 64 keys, loaded ONCE per workgroup (each wave fetches a quarter: 16 registers of prefetch instead of 32)
+//     into double-buffered shared LDS: one workgroup barrier per 64 keys, no second one (buffer i is refilled two barriers on);
+//   * a wave computes BOTH 32-key halves of the tile together: two independent score chains (8 MFMAs), one running-max / rescale
+//     step per 64 keys instead of two, then 8 MFMAs into O -- half as many dependent iterations, twice the work in flight;
+//   * waves whose query block is finished keep loading and keep the barriers (wave-uniform branches only).
+// Same arithmetic per element as attn_fwd_mfma_kernel (scores, exp2, keep hash, bf16 P), only the order of the running-max
+// updates differs (per 64 keys): results agree to fp32 rounding of the rescale factors.
+// MEASURED (round 2, one box, DG_ATTN_SHARED=1 vs 0): T = 256 (B 64, 6 heads): 24.9 us vs 19.9 us with dropout, 17.4 vs 15.2
+// without; T = 1024 (B 8, 12 heads): 68.7 vs 59.3 / 38.6 vs 39.7.  SLOWER: a wave's time is its own instruction stream (about
+// 100 VALU instructions per 32 keys, 56 of them the keep hash, issued in order at 4 cycles each), which "two tiles in flight"
+// does not shorten -- it only removes latency gaps, and those the two other waves of the SIMD already fill -- while the
+// workgroup barrier ties every wave to the slowest one of each step.  What is left for this kernel is fewer instructions per
+// score (the hash), not more overlap.  Kept as an A/B variant; the default stays the per-wave form.
+#define FWD2_BUF 16384                       // per buffer: K row image [64][128 B] + V transposed-read image [64][128 B]
+template <bool DROP>
+__global__ __launch_bounds__(256, 3) void attn_fwd_mfma2_kernel(AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 x FWD2_BUF
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int64_t bh; int blk; bool valid;
+    attn_item(p, wave, bh, blk, valid);
+    if (!valid) return;                                                   // (uniform per workgroup: all four waves share bh)
+    const int qb = blk;                                                   // balanced order only
+    int n_it = 0;                                                         // 64-key steps of the workgroup's longest wave
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        int64_t b2; int k2; bool v2;
+        attn_item(p, w, b2, k2, v2);
+        n_it = max(n_it, (k2 + 2) >> 1);
+    }
+    const int my_it = (qb + 2) >> 1;
+    const int h = (int)(bh % p.NH), b = (int)(bh / p.NH);
+    const int T = p.T, C = p.NH * HD;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16_t* Qb = p.qkv + (int64_t)b * T * ld + h * HD;
+    const bf16_t* Kb = Qb + C;
+    const bf16_t* Vb = Qb + 2 * C;
+    const int q0 = qb * TILE, c = lane & 31, hh = lane >> 5;
+    const int qi = q0 + c;
+
+    bf16x8 qf[4];
+    frags_global(qf, Qb, ld, q0, T, lane);
+    f32x16 O[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { O[0][i] = 0.f; O[1][i] = 0.f; }
+    float m = -INFINITY, lsum = 0.f;
+    const float sc = p.scale * LOG2E;
+    const uint32_t key = DROP ? dg_site_key_dev(p.rng, p.site) : 0u;
+    const uint32_t wbase = ((uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T) + 4u * hh) * DG_WEYL;
+
+    // cooperative loads: a [64 keys][64 d] tile is 512 chunks of 16 B per operand, two per thread
+    u32x4 rk[2], rv[2];
+    const int tid = threadIdx.x;
+    auto load2 = [&](int it) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cc = tid + 256 * i, row = cc >> 3, ch = cc & 7;
+            int gr = it * 64 + row; gr = gr < T ? gr : T - 1;
+            rk[i] = *(const u32x4*)(Kb + (int64_t)gr * ld + ch * 8);
+            rv[i] = *(const u32x4*)(Vb + (int64_t)gr * ld + ch * 8);
+        }
+    };
+    auto store2 = [&](char* buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cc = tid + 256 * i, row = cc >> 3, ch = cc & 7;
+            *(u32x4*)(buf + off_row(row, ch)) = rk[i];
+            *(u32x4*)(buf + 8192 + off_tr(row, ch)) = rv[i];
+        }
+    };
+    // MODE 0: both halves unmasked; 1: first half unmasked, second half on the diagonal (odd query block); 2: first half on the
+    // diagonal, second half entirely in the future = skipped (even query block)
+    auto step = [&](auto mode_tag, int it, const char* buf) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const char* imgK = buf;
+        const char* imgV = buf + 8192;
+        f32x16 Sa, Sb;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { Sa[i] = 0.f; Sb[i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            Sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgK, ks, lane), qf[ks], Sa, 0, 0, 0);
+            if (MODE != 2) Sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgK + 4096, ks, lane), qf[ks], Sb, 0, 0, 0);
+        }
+        const int k0 = it * 64;
+        const uint32_t wta = wbase + (uint32_t)k0 * DG_WEYL, wtb = wta + 32u * DG_WEYL;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float sa = Sa[r] * sc;
+            if (MODE == 2 && k0 + krow(r, hh) > qi) sa = -INFINITY;
+            Sa[r] = sa;
+            mx = fmaxf(mx, sa);
+            if (MODE != 2) {
+                float sb = Sb[r] * sc;
+                if (MODE == 1 && k0 + 32 + krow(r, hh) > qi) sb = -INFINITY;
+                Sb[r] = sb;
+                mx = fmaxf(mx, sb);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t wo = (uint32_t)((r & 3) + 8 * (r >> 2)) * DG_WEYL;
+            float ea = __builtin_amdgcn_exp2f(Sa[r] - mn);
+            ps += ea;
+            if (DROP) ea = dg_keep_w(key, wta + wo, p.thr) ? ea * p.inv_keep : 0.f;
+            Sa[r] = ea;
+            if (MODE != 2) {
+                float eb = __builtin_amdgcn_exp2f(Sb[r] - mn);
+                ps += eb;
+                if (DROP) eb = dg_keep_w(key, wtb + wo, p.thr) ? eb * p.inv_keep : 0.f;
+                Sb[r] = eb;
+            }
+        }
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { O[0][i] *= alpha; O[1][i] *= alpha; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pa = pack8(Sa, s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(imgV, dt, s2, lane), pa, O[dt], 0, 0, 0);
+            if (MODE != 2) {
+                const bf16x8 pb = pack8(Sb, s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(imgV + 4096, dt, s2, lane), pb, O[dt], 0, 0, 0);
+            }
+        }
+    };
+    load2(0);
+    for (int it = 0; it < n_it; ++it) {
+        char* buf = smem + (it & 1) * FWD2_BUF;
+        store2(buf);
+        if (it + 1 < n_it) load2(it + 1);
+        __syncthreads();                       // tile `it` is complete; the other buffer is not touched before the next barrier
+        if (it < my_it) {
+            if (it + 1 < my_it) step(std::integral_constant<int, 0>{}, it, buf);
+            else if (qb & 1) step(std::integral_constant<int, 1>{}, it, buf);
+            else step(std::integral_constant<int, 2>{}, it, buf);
+        }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (hh == 0 && qi < T) p.lse[bh * T + qi] = (m + log2f(lsum)) * (1.f / LOG2E);
+    __syncthreads();                           // every wave is done with the shared tiles: reuse them as private staging
+    store_T_acc(smem + wave * 4096, O, 1.f / lsum, p.out_w + (int64_t)b * T * C + h * HD, C, q0, T, lane);
+}
+
+// =============================================================================================
 // dQ: wave = 32 queries; per key tile: S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T
 #define WAVE_LDS_DQ 12288
 // Without dropout the compiler wants 208 registers for this loop (everything of a tile in flight at once); capped at 168 (three
@@ -596,6 +754,13 @@ int dg_attn_fwd_mfma(const void* qkv, void* out, float* lse, int B, int T, int N
     fill(p, B, T, NH, scale, dp, rng, site);
     p.qkv = (const bf16_t*)qkv; p.out_w = (bf16_t*)out; p.lse = lse;
     dim3 grid((unsigned)((p.n_items + 3) / 4)), block(256);
+    static const int shared_mode = [] { const char* e = getenv("DG_ATTN_SHARED"); return e ? atoi(e) : 0; }();   // 1 = shared 64-key tiles (measured slower, see attn_fwd_mfma2_kernel)
+    if (shared_mode && p.balance && T % 64 == 0) {      // balance: nblk % 4 == 0, i.e. T % 128 == 0 (whole 64-key tiles)
+        if (p.drop) hipLaunchKernelGGL(attn_fwd_mfma2_kernel<true>, grid, block, 2 * FWD2_BUF, s, p);
+        else hipLaunchKernelGGL(attn_fwd_mfma2_kernel<false>, grid, block, 2 * FWD2_BUF, s, p);
+        DG_LAUNCH_CHECK();
+        return DG_OK;
+    }
     if (p.drop) hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_FWD, s, p);
     else hipLaunchKernelGGL(attn_fwd_mfma_kernel<false>, grid, block, 4 * WAVE_LDS_FWD, s, p);
     DG_LAUNCH_CHECK();
