@@ -238,6 +238,29 @@ class TransformerLM(_BlocksLM):
         xa = x if act == torch.float32 else ops.cast(x, act)
         return ops.gemm_nt(xa, w_lm, torch.float32, bias=self.lm_head.bias)
 
+    @torch.no_grad()
+    def _prefill(self, idx, caches, ws, w_lm):
+        """the prompt in ONE pass through the training-forward kernels (not one decode step per position): fills every layer's
+        K/V cache rows [0, t0) and returns the logits (B, V) of the last prompt position -- the values the reference's full
+        forward produces for it (the uncached path runs exactly these kernels)."""
+        act = self.act_dtype
+        B, t0 = idx.shape
+        NH = len(self.blocks[0].sa_head.heads)
+        H = self.blocks[0].sa_head.heads[0].head_size
+        x = ops.embed_fwd(idx, self.token_embedding_table.weight, self.position_embedding_table.weight).view(B * t0, -1)
+        for W, cache in zip(ws, caches):
+            h, _, _ = ops.layernorm_fwd(x, W["ln1w"], W["ln1b"], act)
+            qkv = ops.gemm_nt(h, W["wqkv"], act)
+            cache[:, :t0].copy_(qkv.view(B, t0, -1))
+            o, _ = ops.attn_fwd(qkv, B, t0, NH, H, H ** -0.5, 0.0, None, 0)
+            x = ops.gemm_nt(o, W["wproj"], torch.float32, bias=W["bproj"], residual=x)
+            h, _, _ = ops.layernorm_fwd(x, W["ln2w"], W["ln2b"], act)
+            f = ops.gemm_nt(h, W["w1"], act, bias=W["b1"], relu=True)
+            x = ops.gemm_nt(f, W["w2"], torch.float32, bias=W["b2"], residual=x)
+        last = x.view(B, t0, -1)[:, -1].contiguous()
+        xa = last if act == torch.float32 else ops.cast(last, act)
+        return ops.gemm_nt(xa, w_lm, torch.float32, bias=self.lm_head.bias)
+
     def generate(self, idx, max_new_tokens, generator: Optional[torch.Generator] = None, use_cache: bool = True):
         """ref: src/model.py:611-636.  While the sequence still fits the context window the per-layer K/V of the
         tokens seen so far are kept (training layout, [B, ctx, 3C]) and only the new position is computed; once the
@@ -251,9 +274,7 @@ class TransformerLM(_BlocksLM):
         C3 = 3 * self.token_embedding_table.weight.shape[1]
         ws, w_lm = self._decode_weights()
         caches = [torch.zeros((B, self.context_length, C3), dtype=self.act_dtype, device=idx.device) for _ in self.blocks]
-        logits = None
-        for t in range(t0):                                      # prefill, one position at a time
-            logits = self._decode_step(idx[:, t:t + 1].contiguous(), t, caches, ws, w_lm)
+        logits = self._prefill(idx.contiguous(), caches, ws, w_lm)      # the whole prompt in one pass
         produced = 0
         while produced < max_new_tokens:
             probs = ops.softmax_rows(logits)

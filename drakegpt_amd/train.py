@@ -180,10 +180,9 @@ def main(argv=None):
         engine = TrainEngine(model, B, T, lr=base_lr, betas=params["betas"], seed=42, rank=rank, world_size=world, process_group=pg)
         engine.set_corpus(train_dev)
     else:
-        if world > 1:
-            raise SystemExit("data-parallel training is implemented for TransformerLM (the engine path)")
+        # the five earlier-stage models train through the autograd path; their flat-buffer AdamW all-reduces the gradient
         from .optim import AdamW
-        optimizer = AdamW(model.parameters(), lr=base_lr, betas=params["betas"])
+        optimizer = AdamW(model.parameters(), lr=base_lr, betas=params["betas"], process_group=pg, world_size=world)
 
     model.train()
     sched = {"steps": 0}
@@ -210,7 +209,7 @@ def main(argv=None):
     else:
         from . import ops
         for it in range(args.iters):
-            ix = draw_offsets(len(train_data), T, B, None).to(device, non_blocking=True)
+            ix = ddist.shard_rows(draw_offsets(len(train_data), T, B * world, None), rank, world).to(device, non_blocking=True)
             x, y = ops.batch_gather(train_dev, ix, T)
             logits, loss = model(x, y)
             optimizer.zero_grad()

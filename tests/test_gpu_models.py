@@ -197,3 +197,35 @@ def test_kv_cached_generate_equals_uncached(dev):
         lg = m._decode_step(seq[:, t:t + 1].contiguous(), t, caches, ws, w_lm)
     full, _ = m(seq)
     assert torch.equal(lg, full[:, -1, :])
+
+
+def test_kv_cache_prefill_is_one_pass_and_matches_uncached(dev):
+    """a 17-token prompt: the cache is filled by ONE pass through the training-forward kernels (not 17 decode steps) and the
+    continuation equals the reference algorithm's (full forward per token), in fp32 token for token and logits bit for bit"""
+    import drakegpt_amd as D
+    from drakegpt_amd import ops
+    torch.manual_seed(1)
+    m = D.TransformerLM(V, 64, 48, 4, 2, 0.1).to(dev).eval()
+    g = torch.Generator().manual_seed(4)
+    prompt = torch.randint(0, V, (3, 17), generator=g).to(dev)
+    calls = {"decode": 0}
+    real = ops.attn_decode
+
+    def counting(*a, **k):
+        calls["decode"] += 1
+        return real(*a, **k)
+    ops.attn_decode = counting
+    try:
+        torch.manual_seed(5)
+        b = m.generate(prompt, 9, use_cache=True)
+    finally:
+        ops.attn_decode = real
+    assert calls["decode"] == 8 * 2                            # 8 decode steps x 2 layers; the 17 prompt positions took none
+    torch.manual_seed(5)
+    a = m.generate(prompt, 9, use_cache=False)
+    assert torch.equal(a, b) and a.shape == (3, 26)
+    ws, w_lm = m._decode_weights()
+    caches = [torch.zeros((3, 48, 3 * 64), device=dev) for _ in m.blocks]
+    lg = m._prefill(prompt, caches, ws, w_lm)
+    full, _ = m(prompt)
+    assert torch.equal(lg, full[:, -1, :])
