@@ -18,7 +18,7 @@ DG_F32 = 0
 DG_BF16 = 1
 DG_FP8_E4M3 = 2
 DG_FP8_E5M2 = 3
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class GemmNtArgs(C.Structure):
@@ -91,7 +91,7 @@ SIGNATURES = {
     "dg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
     "dg_attn_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
     "dg_attn_decode": [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
-    "dg_cross_entropy": [_vp, _i64, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _i, _vp],
+    "dg_cross_entropy": [_vp, _i, _i64, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _i, _vp],
     "dg_reduce_sum": [_vp, _i64, _f, _vp, _vp],
     "dg_softmax_rows": [_vp, _i64, _vp, _i64, _i, _i, _vp],
     "dg_adamw_step": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp],

@@ -5,31 +5,31 @@
 // Algorithmic bytes per row: V*4 read (+ V*sizeof(dlogits) written when training).
 #include "common.h"
 
-template <typename TD>
-__global__ void cross_entropy_kernel(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ targets,
+template <typename TD, typename TL = float>
+__global__ void cross_entropy_kernel(const TL* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ targets,
                                      float* __restrict__ loss_rows, TD* __restrict__ dlogits, int64_t ldd,
                                      float grad_scale, const float* __restrict__ gs_dev, int M, int V) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float* x = logits + (int64_t)row * ldl;
+    const TL* x = logits + (int64_t)row * ldl;
     float mx = -INFINITY;
-    for (int i = lane; i < V; i += 64) mx = fmaxf(mx, x[i]);
+    for (int i = lane; i < V; i += 64) mx = fmaxf(mx, (float)x[i]);
     mx = wave_max(mx);
     float s = 0.f;
-    for (int i = lane; i < V; i += 64) s += expf(x[i] - mx);
+    for (int i = lane; i < V; i += 64) s += expf((float)x[i] - mx);
     s = wave_sum(s);
     int64_t t = targets[row];
     t = t < 0 ? 0 : (t >= V ? V - 1 : t);
     const float lse = mx + logf(s);
-    if (lane == 0) loss_rows[row] = lse - x[t];
+    if (lane == 0) loss_rows[row] = lse - (float)x[t];
     if (dlogits) {
         TD* d = dlogits + (int64_t)row * ldd;
         const float inv = 1.f / s;
         if (gs_dev) grad_scale *= gs_dev[0];
         for (int i = lane; i < (int)ldd; i += 64) {
             float g = 0.f;
-            if (i < V) g = (expf(x[i] - mx) * inv - (i == (int)t ? 1.f : 0.f)) * grad_scale;
+            if (i < V) g = (expf((float)x[i] - mx) * inv - (i == (int)t ? 1.f : 0.f)) * grad_scale;
             d[i] = from_f32<TD>(g);
         }
     }
@@ -38,20 +38,26 @@ __global__ void cross_entropy_kernel(const float* __restrict__ logits, int64_t l
 
 #define CE_BLOCK 1024
 #define CE_MAXK 52                    // values per thread (128-VGPR budget at 16 waves per workgroup): rows up to 53248 logits
-template <typename TD>
-__global__ __launch_bounds__(CE_BLOCK) void cross_entropy_row_kernel(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ targets,
-                                                                      float* __restrict__ loss_rows, TD* __restrict__ dlogits, int64_t ldd,
+// TL: logits type.  bf16 logits (the engine at the GPT-2 vocabulary: 0.82 GB instead of 1.65 GB written by lm_head and read here)
+// may be overwritten IN PLACE by their own gradient (dlogits == logits, ldd == ldl): a workgroup holds its whole row in
+// registers before it stores anything.
+template <typename TD, typename TL = float>
+__global__ __launch_bounds__(CE_BLOCK) void cross_entropy_row_kernel(const TL* logits, int64_t ldl, const int64_t* __restrict__ targets,
+                                                                      float* __restrict__ loss_rows, TD* dlogits, int64_t ldd,   // (may alias)
                                                                       float grad_scale, const float* __restrict__ gs_dev, int M, int V) {
     __shared__ float red[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = blockIdx.x;
-    const float* x = logits + (int64_t)row * ldl;
+    const TL* x = logits + (int64_t)row * ldl;
     float v[CE_MAXK];
     float mx = -INFINITY;
+    int64_t t = targets[row];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    const float xt = (float)x[t];                        // before any store of this row (in-place gradient)
 #pragma unroll
     for (int k = 0; k < CE_MAXK; ++k) {
         const int i = k * CE_BLOCK + tid;
-        v[k] = i < V ? x[i] : -INFINITY;
+        v[k] = i < V ? (float)x[i] : -INFINITY;
         mx = fmaxf(mx, v[k]);
     }
     mx = wave_max(mx);
@@ -73,9 +79,7 @@ __global__ __launch_bounds__(CE_BLOCK) void cross_entropy_row_kernel(const float
     s = red[0];
 #pragma unroll
     for (int k = 1; k < 16; ++k) s += red[k];             // fixed order
-    int64_t t = targets[row];
-    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
-    if (tid == 0) loss_rows[row] = mx + logf(s) - x[t];
+    if (tid == 0) loss_rows[row] = mx + logf(s) - xt;
     if (dlogits) {
         TD* d = dlogits + (int64_t)row * ldd;
         const float inv = 1.f / s;
@@ -88,10 +92,24 @@ __global__ __launch_bounds__(CE_BLOCK) void cross_entropy_row_kernel(const float
     }
 }
 
-extern "C" int dg_cross_entropy(const float* logits, int64_t ldl, const int64_t* targets, float* loss_rows,
+extern "C" int dg_cross_entropy(const void* logits_v, int logits_dtype, int64_t ldl, const int64_t* targets, float* loss_rows,
                                 void* dlogits, int64_t ldd, int dtype, float grad_scale, const float* grad_scale_dev, int M, int V, void* stream) {
-    if (!logits || !targets || !loss_rows || M <= 0 || V <= 0 || ldl < V) return DG_ERR_ARG;
+    if (!logits_v || !targets || !loss_rows || M <= 0 || V <= 0 || ldl < V) return DG_ERR_ARG;
     if (dlogits && ldd < V) return DG_ERR_ARG;
+    if (logits_dtype != DG_F32 && logits_dtype != DG_BF16) return DG_ERR_DTYPE;
+    if (logits_dtype == DG_BF16) {
+        // bf16 logits: the whole-row kernel only (its in-place form is what they exist for); gradient in bf16
+        const int64_t w = dlogits && ldd > V ? ldd : V;
+        if (w > (int64_t)CE_BLOCK * CE_MAXK) return DG_ERR_ARG;
+        if (dlogits && dtype != DG_BF16) return DG_ERR_DTYPE;
+        if (dlogits == logits_v && ldd != ldl) return DG_ERR_ARG;
+        hipLaunchKernelGGL((cross_entropy_row_kernel<bf16_t, bf16_t>), dim3(M), dim3(CE_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)logits_v, ldl,
+                           targets, loss_rows, (bf16_t*)dlogits, ldd, grad_scale, grad_scale_dev, M, V);
+        DG_LAUNCH_CHECK();
+        return DG_OK;
+    }
+    const float* logits = (const float*)logits_v;
+    if (dlogits == logits_v) return DG_ERR_ARG;          // in place only with bf16 logits
     dim3 grid((M + 3) / 4), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int64_t width = dlogits && ldd > V ? ldd : V;

@@ -141,7 +141,7 @@ class TrainEngine:
     def __init__(self, model: TransformerLM, batch_size: int, context_length: Optional[int] = None, *,
                  lr: float = 1e-3, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-2,
                  seed: int = 42, rank: int = 0, world_size: int = 1, process_group=None, use_graph: bool = True,
-                 dp_buckets: Optional[int] = None):
+                 dp_buckets: Optional[int] = None, logits: str = "auto"):
         if not isinstance(model, TransformerLM):
             raise TypeError("TrainEngine drives TransformerLM (the other five models train through the autograd path)")
         p0 = next(model.parameters())
@@ -167,6 +167,14 @@ class TrainEngine:
         self.rank, self.world, self.pg = rank, world_size, process_group
         self.use_graph = use_graph
         self._dp_buckets_arg = dp_buckets
+        if logits not in ("auto", "fp32", "bf16"):
+            raise ValueError("logits must be 'auto', 'fp32' or 'bf16'")
+        # logits as bf16 (in-place gradient): by default only where they are big enough to matter -- the GPT-2 vocabulary --
+        # and never in the fp32 parity mode; "fp32" keeps what the module path returns (tests compare the two)
+        V_ = model.token_embedding_table.weight.shape[0]
+        self.bf16_logits = self.act == torch.bfloat16 and 4096 < V_ <= 53248 and logits != "fp32" if logits != "bf16" else True
+        if self.bf16_logits and (self.act != torch.bfloat16 or not (4096 < V_ <= 53248)):
+            raise ValueError("bf16 logits need the bf16 / fp8 precision and a vocabulary of 4097 .. 53248 (the whole-row kernel)")
         g = S.granule(self.act)
         if self.C % g or (self.NH * self.H) % g:
             raise ValueError(f"embedding_dim must be a multiple of {g} for {self.act}")
@@ -440,6 +448,14 @@ class TrainEngine:
                               out_dtype=self.act if (l == self.L - 1 and self.last_block_act) else torch.float32)
             if want_grad:
                 saved.append((sa, sf))
+        if self.bf16_logits and y_idx is not None and not self.keep_logits:
+            # large vocabulary: lm_head writes bf16 logits into the buffer that becomes dlogits -- the cross-entropy kernel holds
+            # a whole row in registers and overwrites it in place with its gradient (1.65 GB less written and 0.82 GB less read
+            # per step at the GPT-2 vocabulary, M = 8192, than fp32 logits + a separate bf16 gradient)
+            buf = torch.empty((M, S.k_pad(self.V, self.act)), dtype=self.act, device=self.dev)
+            logits, (xa,) = S.linear_fwd(run, h, self.param_view("lm.w"), self.param_view("lm.b"), out=buf[:, :self.V])
+            rows = ops.cross_entropy(logits, y_idx.view(M), self.V, dlogits=buf if want_grad else None, grad_scale=1.0 / M)
+            return None, rows, (saved, xa, buf)
         logits, (xa,) = S.linear_fwd(run, h, self.param_view("lm.w"), self.param_view("lm.b"), pad_rows=True)
         if y_idx is None:
             return logits, None, None

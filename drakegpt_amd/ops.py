@@ -455,7 +455,9 @@ def attn_decode(cache: Tensor, t: int, NH: int, H: int, scale: float) -> Tensor:
 
 def cross_entropy(logits: Tensor, targets: Tensor, V: int, dlogits: Optional[Tensor] = None, grad_scale: float = 1.0,
                   grad_scale_dev: Optional[Tensor] = None, loss_rows: Optional[Tensor] = None) -> Tensor:
-    _chk(logits, "logits", torch.float32, contiguous=False)
+    _chk(logits, "logits", contiguous=False)              # fp32, or bf16 (large vocabularies: dlogits may then BE logits)
+    if logits.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("cross_entropy: logits must be float32 or bfloat16")
     _chk(targets, "targets", torch.int64)
     M = logits.shape[0]
     if loss_rows is None:
@@ -464,7 +466,7 @@ def cross_entropy(logits: Tensor, targets: Tensor, V: int, dlogits: Optional[Ten
     if dlogits is not None:
         _chk(dlogits, "dlogits", contiguous=False)
         ldd, dcode = _ld(dlogits), dt_code(dlogits.dtype)
-    check(lib.dg_cross_entropy(_p(logits), _ld(logits), _p(targets), _p(loss_rows), _p(dlogits), ldd, dcode, float(grad_scale),
+    check(lib.dg_cross_entropy(_p(logits), dt_code(logits.dtype), _ld(logits), _p(targets), _p(loss_rows), _p(dlogits), ldd, dcode, float(grad_scale),
                                _p(grad_scale_dev), M, V, _stream()), "dg_cross_entropy")
     return loss_rows
 

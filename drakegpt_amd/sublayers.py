@@ -364,16 +364,15 @@ def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2:
 
 # ------------------------------------------------------------------------------------------------
 # plain Linear (lm_head): y = x W^T + b, fp32 out
-def linear_fwd(run: Run, x2d: Tensor, w: Tensor, b: Optional[Tensor], pad_rows: bool = False):
+def linear_fwd(run: Run, x2d: Tensor, w: Tensor, b: Optional[Tensor], pad_rows: bool = False, out: Optional[Tensor] = None):
     """pad_rows: give the fp32 output a leading dimension that is a multiple of 4 (a strided [M, N] view): with N = 50257 the
     rows of a packed buffer are only 4-byte aligned and the GEMM has to store element by element (2.0 ms instead of 1.0 ms
     for the GPT-2 logits).  Only for callers that consume the result through an `ld`-aware kernel (the engine's cross entropy)."""
     xa = _as_act(run, x2d)
-    out = None
     N = w.shape[0]
-    if pad_rows and N % 4:
+    if out is None and pad_rows and N % 4:
         out = torch.empty((x2d.shape[0], pad_to(N, 4)), dtype=torch.float32, device=x2d.device)[:, :N]
-    y = ops.gemm_nt(xa, run.weights.fwd(w), torch.float32, bias=b, out=out)
+    y = ops.gemm_nt(xa, run.weights.fwd(w), out.dtype if out is not None else torch.float32, bias=b, out=out)
     return y, (xa,)
 
 

@@ -166,12 +166,28 @@ def test_gpt2_small_shape_engine_steps(dev):
     del logits, loss
     m.zero_grad(set_to_none=True)
     torch.cuda.empty_cache()
+    # (a) fp32 logits, as the module path: the two run the same kernels on the same operands
+    eng32 = TrainEngine(m, B, T, lr=0.0, weight_decay=0.0, seed=seed, use_graph=False, logits="fp32")
+    assert not eng32.bf16_logits
+    eng32.set_batch(x, y)
+    l32 = eng32.step().item()
+    g32 = {k: v.detach().clone() for k, v in eng32.named_grads().items()}
+    assert abs(l32 - l_mod) < 1e-5 * l_mod
+    f32 = torch.cat([g32[k].reshape(-1).double() for k in ref])
+    f_ref = torch.cat([ref[k].reshape(-1).double() for k in ref])
+    e32 = ((f32 - f_ref).norm() / f_ref.norm()).item()
+    w32 = max(((k, rel(g32[k], ref[k])) for k in ref), key=lambda kv: kv[1])
+    assert e32 < 1e-5 and w32[1] < 5e-4, (e32, w32)        # measured 4.2e-7 / 3.3e-5 (lm_head.bias: column sums of bf16 dlogits)
+    del eng32, g32, f32
+    torch.cuda.empty_cache()
+    # (b) the default at this vocabulary: bf16 logits overwritten in place by their gradient
     eng = TrainEngine(m, B, T, lr=cfg["base_lr"], betas=cfg["betas"], seed=seed, use_graph=True)
     assert eng.grouped_dw and eng.onehot is None          # V = 50257: the token-table gradient keeps the atomic scatter-add
+    assert eng.bf16_logits
     eng.set_batch(x, y)
     l0 = eng.step().item()
     torch.cuda.synchronize()
-    assert math.isfinite(l0) and abs(l0 - l_mod) < 5e-3 * l_mod
+    assert math.isfinite(l0) and abs(l0 - l_mod) < 1e-3 * l_mod
     assert math.log(V) - 0.5 < l0 < math.log(V) + 3.0, l0
     grads = eng.named_grads()
     assert set(grads) == set(ref)
@@ -181,7 +197,7 @@ def test_gpt2_small_shape_engine_steps(dev):
     worst = max(((k, rel(grads[k], ref[k])) for k in ref), key=lambda kv: kv[1])
     if __import__("os").environ.get("DG_TEST_REPORT"):
         print(f"[parity] gpt2-small engine vs module: flat {e_flat:.3e}, worst tensor {worst}", flush=True)
-    assert e_flat < 1e-5 and worst[1] < 5e-4, (e_flat, worst)        # measured 4.2e-7 / 3.3e-5 (lm_head.bias, as above)
+    assert e_flat < 1e-2 and worst[1] < 3e-2, (e_flat, worst)        # bf16 logits: every gradient sees the 2^-9 rounding of the scores
     # properties: softmax-minus-one-hot rows sum to zero => so does the lm_head bias gradient; token rows that do not occur in the
     # batch get exactly zero; position rows are all used (T = context length)
     gb = grads["lm_head.bias"].double()

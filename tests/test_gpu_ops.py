@@ -474,6 +474,30 @@ def test_cross_entropy_and_reduce(dev):
                 assert torch.all(dl[:, V:] == 0)
 
 
+def test_cross_entropy_bf16_logits_in_place(dev):
+    """large-vocabulary form: bf16 logits [M, ld] overwritten in place by their bf16 gradient (the engine at V = 50257); loss
+    and gradient against fp64 on the same bf16 logits, padding columns zeroed, fp32 logits still refuse to alias"""
+    ops = _ops()
+    M, V, ld = 64, 50257, 50304
+    g = torch.Generator().manual_seed(8)
+    buf = torch.zeros(M, ld, dtype=torch.bfloat16)
+    buf[:, :V] = (torch.randn(M, V, generator=g) * 3).bfloat16()
+    buf[:, V:] = 7.0                                               # stale padding must not survive
+    tgt = torch.randint(0, V, (M,), generator=g)
+    x = buf[:, :V].double()
+    lse = torch.logsumexp(x, 1)
+    ref_loss = lse - x[torch.arange(M), tgt]
+    ref_grad = (torch.softmax(x, 1) - torch.nn.functional.one_hot(tgt, V)) / M
+    d = buf.to(dev)
+    rows = ops.cross_entropy(d[:, :V], tgt.to(dev), V, dlogits=d, grad_scale=1.0 / M)
+    torch.cuda.synchronize()
+    assert rel(rows, ref_loss) < 1e-6
+    assert rel(d[:, :V], ref_grad) < 4e-3 and torch.all(d[:, V:] == 0)
+    lf = torch.randn(8, V, generator=g).to(dev)
+    with pytest.raises(RuntimeError):
+        ops.cross_entropy(lf, tgt[:8].to(dev), V, dlogits=lf)
+
+
 def test_embed(dev):
     ops = _ops()
     B, T, C, V = 5, 8, 32, 80
