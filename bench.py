@@ -165,6 +165,7 @@ def main():
         extra = {}
         for name, cname, b, p_drop, st, wu, prec in (("scaled_dropout0", "scaled", B, 0.0, 30, 5, "bf16"), ("scaled_B256", "scaled", 256, None, 20, 5, "bf16"),
                                                      ("gpt2_small_B8", "gpt2_small", 8, None, 8, 3, "bf16"),
+                                                     ("gpt2_small_B16", "gpt2_small", 16, None, 5, 2, "bf16"),
                                                      ("gpt2_medium_B8_bf16", "gpt2_medium", 8, None, 5, 2, "bf16"),
                                                      ("gpt2_medium_B8_fp8", "gpt2_medium", 8, None, 5, 2, "fp8")):
             try:
@@ -274,7 +275,7 @@ def kernel_roofline(eng, offsets, peak_tflops):
             elif to == "bf16" and opts == [True, True, False, False, False, False, True]: epi = 2
             elif opts == [True, False, False, True, True, False, False]: epi = 3
             elif to == "bf16" and opts == [False, False, False, False, False, True, False]: epi = 6 if has("colsum_part") else 4
-            elif to == "float" and opts == [True, False, False, False, False, False, False]: epi = 5
+            elif opts == [True, False, False, False, False, False, False]: epi = 5
             elif opts == [True, False, False, False, True, False, False]: epi = 7
             else: epi = 0
             sym = f"gemm_nt_ws_kernel<{to},{'true' if pf else 'false'},{nj},{epi}{',fp8' if f8 else ''}>"      # dispatch rule of dg_gemm_nt

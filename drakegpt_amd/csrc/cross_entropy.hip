@@ -92,6 +92,75 @@ __global__ __launch_bounds__(CE_BLOCK) void cross_entropy_row_kernel(const TL* l
     }
 }
 
+// bf16 logits, vectorised: a thread owns 16-byte chunks (8 logits) c = tid + 1024 j of its row, j < CE_MAXC: 16-byte loads and
+// stores (the 2-byte-per-lane form of the generic kernel ran at half the rate of the fp32 one: 1240 us instead of 636 us for
+// M = 8192 rows of 50257).  ldl % 8 == 0 and a 16-byte aligned base; may run in place (dlogits == logits).
+#define CE_MAXC 7                     // 7 x 1024 x 8 = 57344 >= 53248
+__global__ __launch_bounds__(CE_BLOCK) void cross_entropy_row_bf16_kernel(const bf16_t* logits, int64_t ldl, const int64_t* __restrict__ targets,
+                                                                           float* __restrict__ loss_rows, bf16_t* dlogits, int64_t ldd,
+                                                                           float grad_scale, const float* __restrict__ gs_dev, int M, int V) {
+    __shared__ float red[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row = blockIdx.x;
+    const bf16_t* x = logits + (int64_t)row * ldl;
+    int64_t t = targets[row];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    const float xt = (float)x[t];                        // before any store of this row (in-place gradient)
+    const int nchunk = (int)((dlogits && ldd > V ? ldd : (int64_t)V) + 7) / 8;      // chunks that exist in memory (ldl >= that * 8)
+    float v[CE_MAXC][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < CE_MAXC; ++j) {
+        const int c = tid + CE_BLOCK * j;
+        if (c < nchunk && c * 8 < V) {
+            const bf16x8 q = *(const bf16x8*)(x + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[j][e] = (c * 8 + e < V) ? (float)q[e] : -INFINITY; mx = fmaxf(mx, v[j][e]); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[j][e] = -INFINITY;
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mx = fmaxf(mx, red[k]);
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CE_MAXC; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[j][e] = expf(v[j][e] - mx); s += v[j][e]; }
+    s = wave_sum(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    s = red[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k];             // fixed order
+    if (tid == 0) loss_rows[row] = mx + logf(s) - xt;
+    if (dlogits) {
+        bf16_t* d = dlogits + (int64_t)row * ldd;
+        const float inv = 1.f / s;
+        if (gs_dev) grad_scale *= gs_dev[0];
+        const int dchunk = (int)(ldd / 8);
+#pragma unroll
+        for (int j = 0; j < CE_MAXC; ++j) {
+            const int c = tid + CE_BLOCK * j;
+            if (c < dchunk) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = c * 8 + e;
+                    o[e] = (bf16_t)(i < V ? (v[j][e] * inv - (i == (int)t ? 1.f : 0.f)) * grad_scale : 0.f);
+                }
+                *(bf16x8*)(d + c * 8) = o;
+            }
+        }
+    }
+}
+
 extern "C" int dg_cross_entropy(const void* logits_v, int logits_dtype, int64_t ldl, const int64_t* targets, float* loss_rows,
                                 void* dlogits, int64_t ldd, int dtype, float grad_scale, const float* grad_scale_dev, int M, int V, void* stream) {
     if (!logits_v || !targets || !loss_rows || M <= 0 || V <= 0 || ldl < V) return DG_ERR_ARG;
@@ -103,8 +172,14 @@ extern "C" int dg_cross_entropy(const void* logits_v, int logits_dtype, int64_t 
         if (w > (int64_t)CE_BLOCK * CE_MAXK) return DG_ERR_ARG;
         if (dlogits && dtype != DG_BF16) return DG_ERR_DTYPE;
         if (dlogits == logits_v && ldd != ldl) return DG_ERR_ARG;
-        hipLaunchKernelGGL((cross_entropy_row_kernel<bf16_t, bf16_t>), dim3(M), dim3(CE_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)logits_v, ldl,
-                           targets, loss_rows, (bf16_t*)dlogits, ldd, grad_scale, grad_scale_dev, M, V);
+        const bool vec = ldl % 8 == 0 && dg_aligned16(logits_v) && (!dlogits || (ldd % 8 == 0 && dg_aligned16(dlogits))) &&
+                         (int64_t)((V + 7) / 8) * 8 <= ldl && w <= (int64_t)CE_BLOCK * CE_MAXC * 8;
+        if (vec)
+            hipLaunchKernelGGL(cross_entropy_row_bf16_kernel, dim3(M), dim3(CE_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)logits_v, ldl,
+                               targets, loss_rows, (bf16_t*)dlogits, ldd, grad_scale, grad_scale_dev, M, V);
+        else
+            hipLaunchKernelGGL((cross_entropy_row_kernel<bf16_t, bf16_t>), dim3(M), dim3(CE_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)logits_v, ldl,
+                               targets, loss_rows, (bf16_t*)dlogits, ldd, grad_scale, grad_scale_dev, M, V);
         DG_LAUNCH_CHECK();
         return DG_OK;
     }

@@ -319,7 +319,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
                 else if (a->out_dtype == DG_BF16 && a->bias && a->relu && a->sign_bits_out && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits) epi = 2;
                 else if (a->bias && p.drop && a->residual && !a->relu && !a->relu_mask && !a->sign_bits && !a->sign_bits_out) epi = 3;
                 else if (a->out_dtype == DG_BF16 && pf && !a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits_out) epi = a->colsum_part ? 6 : 4;
-                else if (a->out_dtype == DG_F32 && a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits && !a->sign_bits_out) epi = 5;
+                else if (a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits && !a->sign_bits_out) epi = 5;
                 else if (a->bias && !p.drop && a->residual && !a->relu && !a->relu_mask && !a->sign_bits && !a->sign_bits_out) epi = 7;
             }
         }
@@ -336,6 +336,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
             else if (epi == 3 && a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, NJ_, 3>), pgrid, wsb, 0, s, p); \
             else if (epi == 3) hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, NJ_, 3>), pgrid, wsb, 0, s, p); \
             else if (epi == 4) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true, NJ_, 4>), pgrid, wsb, 0, s, p); \
+            else if (epi == 5 && a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, NJ_, 5>), pgrid, wsb, 0, s, p); \
             else if (epi == 5) hipLaunchKernelGGL((gemm_nt_ws_kernel<float, false, NJ_, 5>), pgrid, wsb, 0, s, p); \
             else if (epi == 6) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, true, NJ_, 6>), pgrid, wsb, 0, s, p); \
             else if (epi == 7 && a->out_dtype == DG_BF16) hipLaunchKernelGGL((gemm_nt_ws_kernel<bf16_t, false, NJ_, 7>), pgrid, wsb, 0, s, p); \

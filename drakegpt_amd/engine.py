@@ -167,6 +167,9 @@ class TrainEngine:
         self.rank, self.world, self.pg = rank, world_size, process_group
         self.use_graph = use_graph
         self._dp_buckets_arg = dp_buckets
+        import os as _os
+        if logits == "auto" and _os.environ.get("DG_LOGITS") in ("fp32", "bf16"):      # A/B runs
+            logits = _os.environ["DG_LOGITS"]
         if logits not in ("auto", "fp32", "bf16"):
             raise ValueError("logits must be 'auto', 'fp32' or 'bf16'")
         # logits as bf16 (in-place gradient): by default only where they are big enough to matter -- the GPT-2 vocabulary --
