@@ -66,8 +66,10 @@ def test_constructor_signatures_are_positional_like_the_reference():
     t = D.TransformerLM(V, 32, 8, 4, 3, 0.1)
     assert t.context_length == 8 and hasattr(t, "ln_f")
     assert [blk.layer_index for blk in t.blocks] == [0, 1, 2]
+    f8 = D.TransformerLM(V, 32, 8, 4, 3, 0.1, precision="fp8")      # round 2: bf16 activations + fp8 operands for the block Linears
+    assert f8.fp8 and f8.act_dtype == torch.bfloat16 and f8.blocks[0].sa_head.run_mode == "fp8" and not t.fp8
     with pytest.raises(ValueError):
-        D.TransformerLM(V, 32, 8, 4, 3, 0.1, precision="fp8")
+        D.TransformerLM(V, 32, 8, 4, 3, 0.1, precision="fp16")
 
 
 def test_no_cpu_fallback_and_no_oracle_import_in_product():
