@@ -278,7 +278,8 @@ def kernel_roofline(eng, offsets, peak_tflops):
             elif opts == [True, False, False, False, False, False, False]: epi = 5
             elif opts == [True, False, False, False, True, False, False]: epi = 7
             else: epi = 0
-            sym = f"gemm_nt_ws_kernel<{to},{'true' if pf else 'false'},{nj},{epi}{',fp8' if f8 else ''}>"      # dispatch rule of dg_gemm_nt
+            f8code = 0 if not f8 else (2 if A.dtype == torch.float8_e5m2 else 1)
+            sym = f"gemm_nt_ws_kernel<{to},{'true' if pf else 'false'},{nj},{epi},{f8code}>"      # dispatch rule of dg_gemm_nt
         else:
             sym = f"gemm_nt_kernel<{'bf16' if A.dtype == torch.bfloat16 else 'float'},{to}>"
         kw2 = dict(kw)
@@ -299,7 +300,7 @@ def kernel_roofline(eng, offsets, peak_tflops):
         problems = list(problems)
         real_tng(problems, workspace)
         fl = sum(2.0 * A.shape[0] * P * Q for A, _, _, P, Q in problems)
-        sym = "gemm_tn_grouped_kernel" if os.environ.get("DG_TN_TILE") == "128" else "gemm_tn_grouped256_kernel"
+        sym = "gemm_tn_grouped_kernel" if os.environ.get("DG_TN_TILE") == "128" else f"gemm_tn_grouped256_kernel<{1 if os.environ.get('DG_TN_WAVETILE') == '1' else 0}>"
         calls.append((sym, fl, lambda: real_tng(problems, workspace)))
 
     # HBM-bound kernels: algorithmic bytes per launch (what the kernel must read + write once; SURVEY 8d conventions)
