@@ -18,7 +18,7 @@ DG_F32 = 0
 DG_BF16 = 1
 DG_FP8_E4M3 = 2
 DG_FP8_E5M2 = 3
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class GemmNtArgs(C.Structure):
@@ -66,10 +66,10 @@ SIGNATURES = {
     "dg_state_advance": [_vp, _vp],
     "dg_batch_gather": [_vp, _i64, _vp, _vp, _vp, _i, _i, _vp],
     "dg_embed_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp],
-    "dg_embed_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "dg_embed_bwd": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "dg_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp],
     "dg_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
-    "dg_layernorm_bwd_fused": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _vp, _u32, _vp, _vp],
+    "dg_layernorm_bwd_fused": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _vp, _u32, _vp, _vp],
     "dg_gemm_nt": [C.POINTER(GemmNtArgs), _vp],
     "dg_gemm_nt_sign_bits_supported": [C.POINTER(GemmNtArgs)],
     "dg_gemm_nt_colsum_supported": [C.POINTER(GemmNtArgs)],
@@ -83,7 +83,7 @@ SIGNATURES = {
     "dg_gemm_tn_grouped_workspace_bytes": [C.POINTER(TnProblem), _i],
     "dg_reduce_partials": [_vp, _i64, _i, _vp, _i64, _vp],
     "dg_colsum": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _vp],
-    "dg_dropout_bwd_cast": [_vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp, _u32, _vp, _i64, _vp, _i64, _i, _vp],
+    "dg_dropout_bwd_cast": [_vp, _i, _i64, _vp, _i64, _i, _i, _i, _f, _vp, _u32, _vp, _i64, _vp, _i64, _i, _vp],
     "dg_cast": [_vp, _i, _vp, _i, _i64, _vp],
     "dg_transpose_cast": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp],
     "dg_transpose_cast_batched": [_vp, _i, _i, _i, _i, _vp],

@@ -99,7 +99,8 @@ extern "C" int dg_embed_fwd(const int64_t* idx, const float* tok, const float* p
 
 // token table: scatter-add rows with fp32 atomics (one dword per lane, contiguous per wave:
 // the shape the atomic units like -- microarch "Global float atomics")
-__global__ void embed_bwd_tok_kernel(const int64_t* __restrict__ idx, const float* __restrict__ dx,
+template <typename TX>
+__global__ void embed_bwd_tok_kernel(const int64_t* __restrict__ idx, const TX* __restrict__ dx,
                                      float* __restrict__ dtok, int64_t M, int C, int V) {
     int64_t total = M * C;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -108,13 +109,14 @@ __global__ void embed_bwd_tok_kernel(const int64_t* __restrict__ idx, const floa
         int c = (int)(i % C);
         int64_t v = idx[m];
         v = v < 0 ? 0 : (v >= V ? V - 1 : v);
-        atomicAdd(dtok + v * C + c, dx[i]);
+        atomicAdd(dtok + v * C + c, (float)dx[i]);
     }
 }
 // position table: dpos[t,c] = sum_b dx[b,t,c]   (fixed order: deterministic).  256 threads = 64 float4 columns x 4 batch
 // groups (group g sums b = g, g+4, ...), combined through LDS: the one-thread-per-element form walked the B strided rows
 // serially (17 us for 25 MB once nothing had pulled dx into the caches).
-__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* __restrict__ dx, float* __restrict__ dpos,
+template <typename TX>
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const TX* __restrict__ dx, float* __restrict__ dpos,
                                                             int B, int T, int C) {
     __shared__ f32x4 red[4][64];
     const int64_t tc = (int64_t)T * C;
@@ -124,12 +126,16 @@ __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* __restr
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i < tc) {
         if (vec) {
-            for (int b = g; b < B; b += 4) s += *(const f32x4*)(dx + (int64_t)b * tc + i);
+            typedef TX TX4 __attribute__((ext_vector_type(4)));
+            for (int b = g; b < B; b += 4) {
+                const TX4 t = *(const TX4*)(dx + (int64_t)b * tc + i);
+                s += (f32x4){(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+            }
         } else {
             for (int b = g; b < B; b += 4)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (i + e < tc) s[e] += dx[(int64_t)b * tc + i + e];
+                    if (i + e < tc) s[e] += (float)dx[(int64_t)b * tc + i + e];
         }
     }
     red[g][lane] = s;
@@ -141,8 +147,10 @@ __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* __restr
             if (i + e < tc) dpos[i + e] = t[e];
     }
 }
-extern "C" int dg_embed_bwd(const int64_t* idx, const float* dx, float* dtok, float* dpos,
+extern "C" int dg_embed_bwd(const int64_t* idx, const void* dx_v, int dx_dtype, float* dtok, float* dpos,
                             int B, int T, int C, int V, void* stream) {
+    if (dx_dtype != DG_F32 && dx_dtype != DG_BF16) return DG_ERR_DTYPE;
+    const float* dx = (const float*)dx_v;
     if (!idx || !dx || (!dtok && !dpos) || B <= 0 || T <= 0 || C <= 0 || V <= 0) return DG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int64_t M = (int64_t)B * T;
@@ -152,12 +160,16 @@ extern "C" int dg_embed_bwd(const int64_t* idx, const float* dx, float* dtok, fl
         int64_t total = M * C;
         unsigned grid = (unsigned)((total + 255) / 256);
         if (grid > 8192) grid = 8192;
-        hipLaunchKernelGGL(embed_bwd_tok_kernel, dim3(grid), dim3(256), 0, s, idx, dx, dtok, M, C, V);
+        if (dx_dtype == DG_BF16) hipLaunchKernelGGL(embed_bwd_tok_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, idx, (const bf16_t*)dx_v, dtok, M, C, V);
+        else hipLaunchKernelGGL(embed_bwd_tok_kernel<float>, dim3(grid), dim3(256), 0, s, idx, dx, dtok, M, C, V);
         DG_LAUNCH_CHECK();
     }
     if (dpos) {
         int64_t tc = (int64_t)T * C;
-        hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, s, dx, dpos, B, T, C);   // 256 elements per workgroup
+        if (dx_dtype == DG_BF16)
+            hipLaunchKernelGGL(embed_bwd_pos_kernel<bf16_t>, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, s, (const bf16_t*)dx_v, dpos, B, T, C);
+        else
+            hipLaunchKernelGGL(embed_bwd_pos_kernel<float>, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, s, dx, dpos, B, T, C);   // 256 elements per workgroup
         DG_LAUNCH_CHECK();
     }
     return DG_OK;
@@ -400,11 +412,13 @@ __global__ void dropbwd_cast_kernel(const TI* __restrict__ dy, int64_t lddy, TO*
 
 static inline int rows_per_partial(int M, int n_partials) { return (M + n_partials - 1) / n_partials; }
 
-extern "C" int dg_dropout_bwd_cast(const float* dy, int64_t lddy, void* g, int64_t ldg, int dtype,
+extern "C" int dg_dropout_bwd_cast(const void* dy, int dy_dtype, int64_t lddy, void* g, int64_t ldg, int dtype,
                                    int M, int N, float p, const uint32_t* rng_state, uint32_t site,
                                    const float* relu_mask, int64_t ldmask,
                                    float* colsum_part, int64_t part_stride, int n_partials, void* stream) {
     if (!dy || M <= 0 || N <= 0 || (!g && !colsum_part)) return DG_ERR_ARG;
+    if (dy_dtype != DG_F32 && dy_dtype != DG_BF16) return DG_ERR_DTYPE;
+    if (dy_dtype == DG_BF16 && (dtype != DG_BF16 || relu_mask)) return DG_ERR_ARG;    // bf16 in: the engine's gradient stream -> bf16 operand
     if (colsum_part && n_partials <= 0) return DG_ERR_ARG;
     if (!colsum_part) n_partials = M < 1024 ? 1 : (M / 64 > 1024 ? 1024 : M / 64);
     int rows_per = rows_per_partial(M, n_partials);
@@ -414,11 +428,14 @@ extern "C" int dg_dropout_bwd_cast(const float* dy, int64_t lddy, void* g, int64
     uint32_t thr = dg_drop_threshold(p);
     dim3 grid(n_partials, (N + 255) / 256), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(TO, DROP) hipLaunchKernelGGL((dropbwd_cast_kernel<float, TO, DROP>), grid, block, 0, s, dy, lddy, (TO*)g, ldg, M, N, inv_keep, thr, rng_state, site, relu_mask, ldmask, colsum_part, part_stride, rows_per)
-    if (dtype == DG_BF16) { if (drop) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
+#define LAUNCH(TO, DROP) hipLaunchKernelGGL((dropbwd_cast_kernel<float, TO, DROP>), grid, block, 0, s, (const float*)dy, lddy, (TO*)g, ldg, M, N, inv_keep, thr, rng_state, site, relu_mask, ldmask, colsum_part, part_stride, rows_per)
+#define LAUNCH_BB(DROP) hipLaunchKernelGGL((dropbwd_cast_kernel<bf16_t, bf16_t, DROP>), grid, block, 0, s, (const bf16_t*)dy, lddy, (bf16_t*)g, ldg, M, N, inv_keep, thr, rng_state, site, relu_mask, ldmask, colsum_part, part_stride, rows_per)
+    if (dy_dtype == DG_BF16) { if (drop) LAUNCH_BB(true); else LAUNCH_BB(false); }
+    else if (dtype == DG_BF16) { if (drop) LAUNCH(bf16_t, true); else LAUNCH(bf16_t, false); }
     else if (dtype == DG_F32) { if (drop) LAUNCH(float, true); else LAUNCH(float, false); }
     else return DG_ERR_DTYPE;
 #undef LAUNCH
+#undef LAUNCH_BB
     DG_LAUNCH_CHECK();
     return DG_OK;
 }

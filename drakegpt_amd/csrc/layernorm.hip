@@ -119,11 +119,14 @@ extern "C" int dg_layernorm_fwd(const float* x, const float* gamma, const float*
 struct LnFuse {
     void* g; float* gbias_part; float inv_keep; uint32_t thr; int drop; const uint32_t* rng; uint32_t site;
 };
-template <typename TD /* dy: float, or bf16 on the vector path */, bool VEC, int LN_MAXV, int NTHREADS, int FUSE_G /*0 none, 1 bf16, 2 f32*/>
+// TR: type of the residual-branch gradient stream (dresid in, dx out): float, or bf16 on the vector path -- the engine's bf16 /
+// fp8 modes keep the stream in bf16 (it is rounded once per sub-layer, like every other activation gradient of those modes):
+// 75 MB instead of 100 MB per launch at the scaled configuration.
+template <typename TD /* dy: float, or bf16 on the vector path */, bool VEC, int LN_MAXV, int NTHREADS, int FUSE_G /*0 none, 1 bf16, 2 f32*/, typename TR = float>
 __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* __restrict__ dy, const float* __restrict__ x,
                               const float* __restrict__ gamma, const float* __restrict__ mean,
-                              const float* __restrict__ rstd, const float* __restrict__ dresid,
-                              float* __restrict__ dx, float* __restrict__ dgamma_part,
+                              const float* __restrict__ rstd, const TR* __restrict__ dresid,
+                              TR* __restrict__ dx, float* __restrict__ dgamma_part,
                               float* __restrict__ dbeta_part, int64_t part_stride,
                               int M, int C, int rows_per) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][NW][C]
@@ -154,11 +157,13 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
             float s1 = 0.f, s2 = 0.f;
             // the residual-branch gradient is requested together with dy and x, not after the two reductions (that cost a
             // second HBM round trip per row)
-            const f32x4* drr = dresid ? (const f32x4*)(dresid + (int64_t)row * C) : nullptr;
+            typedef TR TR4 __attribute__((ext_vector_type(4)));
+            const TR4* drr = dresid ? (const TR4*)(dresid + (int64_t)row * C) : nullptr;
 #pragma unroll
             for (int k = 0; k < LN_MAXV; ++k) {
                 const int i = lane + k * 64;
-                drv[k] = (drr && i < nv) ? drr[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (drr && i < nv) { const TR4 t = drr[i]; drv[k] = (f32x4){(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
+                else drv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int k = 0; k < LN_MAXV; ++k) {
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
                 }
             }
             const float c1 = wave_sum(s1) * invC, c2 = wave_sum(s2) * invC;
-            f32x4* dxr = (f32x4*)(dx + (int64_t)row * C);
+            TR4* dxr = (TR4*)(dx + (int64_t)row * C);
 #pragma unroll
             for (int k = 0; k < LN_MAXV; ++k) {
                 int i = lane + k * 64;
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = rs * (gv[k][j] - c1 - xh[k][j] * c2);
                     o += drv[k];
-                    dxr[i] = o;
+                    if constexpr (sizeof(TR) == 4) dxr[i] = o;
+                    else dxr[i] = (TR4){(TR)o[0], (TR)o[1], (TR)o[2], (TR)o[3]};
                     if (FUSE_G) {
                         f32x4 gq = o;
                         if (fz.drop) {
@@ -248,8 +254,8 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
             for (int c = lane; c < C; c += 64) {
                 float h = (xr[c] - mu) * rs, gg = (float)dyr[c] * gamma[c];
                 float o = rs * (gg - c1 - h * c2);
-                if (dresid) o += dresid[(int64_t)row * C + c];
-                dx[(int64_t)row * C + c] = o;
+                if (dresid) o += (float)dresid[(int64_t)row * C + c];
+                dx[(int64_t)row * C + c] = (TR)o;
             }
         }
         __syncthreads();
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
 }
 
 static int ln_bwd_launch(LnFuse fz, int fuse, const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
-                         const float* rstd, const float* dresid, float* dx,
+                         const float* rstd, const void* dresid, void* dx, int resid_dtype,
                          float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
                          int M, int C, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma_part || !dbeta_part) return DG_ERR_ARG;
@@ -275,6 +281,8 @@ static int ln_bwd_launch(LnFuse fz, int fuse, const void* dy, int dy_dtype, cons
     const int nk = (C / 4 + 63) / 64;
     if (fuse && (!vec || nk > 4 || !fz.g || !dg_aligned16(fz.g))) return DG_ERR_ARG;
     if (dy_dtype == DG_BF16 && !vec) return DG_ERR_ARG;         // bf16 gradients only on the vector path
+    if (resid_dtype != DG_F32 && resid_dtype != DG_BF16) return DG_ERR_DTYPE;
+    if (resid_dtype == DG_BF16 && (!vec || fuse != 1 || dy_dtype != DG_BF16)) return DG_ERR_ARG;   // bf16 stream: the engine's fused bf16 form only
     // more waves per workgroup = more rows in flight per partial (HBM-bound: needs the occupancy)
     int nthreads = C <= 512 ? 1024 : (C <= 1024 ? 512 : 256);
     size_t lds_bytes = (size_t)2 * (nthreads / 64) * C * sizeof(float);    // (the vector path uses half of it)
@@ -282,7 +290,13 @@ static int ln_bwd_launch(LnFuse fz, int fuse, const void* dy, int dy_dtype, cons
     dim3 grid(n_partials), block(nthreads);
     hipStream_t s = (hipStream_t)stream;
     if (lds_bytes > 64 * 1024) return DG_ERR_ARG;   // C <= 2048 on either path
-#define LAUNCH_T(TD, V, K, NT, F) hipLaunchKernelGGL((ln_bwd_kernel<TD, V, K, NT, F>), grid, block, lds_bytes, s, fz, (const TD*)dy, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part, part_stride, M, C, rows_per)
+#define LAUNCH_T(TD, V, K, NT, F) hipLaunchKernelGGL((ln_bwd_kernel<TD, V, K, NT, F>), grid, block, lds_bytes, s, fz, (const TD*)dy, x, gamma, mean, rstd, (const float*)dresid, (float*)dx, dgamma_part, dbeta_part, part_stride, M, C, rows_per)
+#define LAUNCH_B(K, NT) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, true, K, NT, 1, bf16_t>), grid, block, lds_bytes, s, fz, (const bf16_t*)dy, x, gamma, mean, rstd, (const bf16_t*)dresid, (bf16_t*)dx, dgamma_part, dbeta_part, part_stride, M, C, rows_per)
+    if (resid_dtype == DG_BF16) {
+        if (nk <= 1) LAUNCH_B(1, 1024); else if (nk == 2) LAUNCH_B(2, 1024); else if (nk == 3) LAUNCH_B(3, 512); else LAUNCH_B(4, 512);
+        DG_LAUNCH_CHECK();
+        return DG_OK;
+    }
 #define LAUNCH(V, K, NT, F) do { if (dy_dtype == DG_BF16) LAUNCH_T(bf16_t, true, K, NT, F); else LAUNCH_T(float, V, K, NT, F); } while (0)
     if (fuse == 0) {
         if (!vec) { if (nthreads == 1024) LAUNCH_T(float, false, 1, 1024, 0); else if (nthreads == 512) LAUNCH_T(float, false, 1, 512, 0); else LAUNCH_T(float, false, 1, 256, 0); }
@@ -299,6 +313,7 @@ static int ln_bwd_launch(LnFuse fz, int fuse, const void* dy, int dy_dtype, cons
         else if (nk == 3) LAUNCH(true, 3, 512, 2); else LAUNCH(true, 4, 512, 2);
     }
 #undef LAUNCH_T
+#undef LAUNCH_B
 #undef LAUNCH
     DG_LAUNCH_CHECK();
     return DG_OK;
@@ -309,11 +324,11 @@ extern "C" int dg_layernorm_bwd(const void* dy, int dy_dtype, const float* x, co
                                 float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
                                 int M, int C, void* stream) {
     LnFuse fz = {};
-    return ln_bwd_launch(fz, 0, dy, dy_dtype, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part, part_stride, n_partials, M, C, stream);
+    return ln_bwd_launch(fz, 0, dy, dy_dtype, x, gamma, mean, rstd, dresid, dx, DG_F32, dgamma_part, dbeta_part, part_stride, n_partials, M, C, stream);
 }
 
 extern "C" int dg_layernorm_bwd_fused(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
-                                      const float* rstd, const float* dresid, float* dx,
+                                      const float* rstd, const void* dresid, void* dx, int resid_dtype,
                                       float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
                                       int M, int C,
                                       void* g, int g_dtype, float dropout_p, const uint32_t* rng_state, uint32_t site,
@@ -326,6 +341,6 @@ extern "C" int dg_layernorm_bwd_fused(const void* dy, int dy_dtype, const float*
     fz.inv_keep = 1.f / (1.f - dropout_p);
     fz.thr = dg_drop_threshold(dropout_p);
     fz.rng = rng_state; fz.site = site;
-    return ln_bwd_launch(fz, g_dtype == DG_BF16 ? 1 : 2, dy, dy_dtype, x, gamma, mean, rstd, dresid, dx, dgamma_part, dbeta_part,
+    return ln_bwd_launch(fz, g_dtype == DG_BF16 ? 1 : 2, dy, dy_dtype, x, gamma, mean, rstd, dresid, dx, resid_dtype, dgamma_part, dbeta_part,
                          part_stride, n_partials, M, C, stream);
 }

@@ -141,7 +141,7 @@ class TrainEngine:
     def __init__(self, model: TransformerLM, batch_size: int, context_length: Optional[int] = None, *,
                  lr: float = 1e-3, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-2,
                  seed: int = 42, rank: int = 0, world_size: int = 1, process_group=None, use_graph: bool = True,
-                 dp_buckets: Optional[int] = None, logits: str = "auto"):
+                 dp_buckets: Optional[int] = None, logits: str = "auto", grad_stream: str = "auto"):
         if not isinstance(model, TransformerLM):
             raise TypeError("TrainEngine drives TransformerLM (the other five models train through the autograd path)")
         p0 = next(model.parameters())
@@ -170,6 +170,18 @@ class TrainEngine:
         import os as _os
         if logits == "auto" and _os.environ.get("DG_LOGITS") in ("fp32", "bf16"):      # A/B runs
             logits = _os.environ["DG_LOGITS"]
+        if grad_stream == "auto" and _os.environ.get("DG_GRAD_STREAM") in ("fp32", "bf16"):
+            grad_stream = _os.environ["DG_GRAD_STREAM"]
+        if grad_stream not in ("auto", "fp32", "bf16"):
+            raise ValueError("grad_stream must be 'auto', 'fp32' or 'bf16'")
+        # The gradient that flows down the residual branch (dresid -> dx of every LayerNorm backward).  bf16 / fp8 modes keep it
+        # in bf16 ("auto"): it is rounded once per sub-layer like every other activation gradient of those modes, and every
+        # LayerNorm backward moves 75 MB instead of 100 MB.  The forward residual stream stays fp32 in every mode.
+        _C = model.token_embedding_table.weight.shape[1]
+        _can = self.act == torch.bfloat16 and ops.layernorm_bwd_fused_supported(_C) and self.M % 64 == 0
+        if grad_stream == "bf16" and not _can:
+            raise ValueError("a bf16 gradient stream needs the bf16 / fp8 precision and the fused LayerNorm backward")
+        self.stream_dtype = torch.bfloat16 if (_can and grad_stream != "fp32") else torch.float32
         if logits not in ("auto", "fp32", "bf16"):
             raise ValueError("logits must be 'auto', 'fp32' or 'bf16'")
         # logits as bf16 (in-place gradient): by default only where they are big enough to matter -- the GPT-2 vocabulary --
@@ -526,7 +538,7 @@ class TrainEngine:
         if seed:
             self._fp8_seeded = True
         return S.Run(act=self.act, rng=self.state if self.p_drop > 0.0 else None, weights=self.weights, fp8=self.fp8,
-                     fp8_sites=self.fp8_sites if self.fp8 else None, fp8_seed=seed, step_word=self.state)
+                     fp8_sites=self.fp8_sites if self.fp8 else None, fp8_seed=seed, step_word=self.state, stream=self.stream_dtype)
 
     def _prog_fwd_bwd(self):
         """gather the batch, forward, backward, reduce the gradient partials"""

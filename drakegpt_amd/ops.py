@@ -114,7 +114,7 @@ def embed_fwd(idx: Tensor, tok: Tensor, pos: Optional[Tensor], out: Optional[Ten
 
 def embed_bwd(idx: Tensor, dx: Tensor, dtok: Optional[Tensor], dpos: Optional[Tensor], V: Optional[int] = None) -> None:
     _chk(idx, "idx", torch.int64)
-    _chk(dx, "dx", torch.float32)
+    _chk(dx, "dx")                         # fp32, or the engine's bf16 gradient stream
     B, T = idx.shape
     if dtok is not None:
         _chk(dtok, "dtok", torch.float32)
@@ -125,7 +125,7 @@ def embed_bwd(idx: Tensor, dx: Tensor, dtok: Optional[Tensor], dpos: Optional[Te
         _chk(dpos, "dpos", torch.float32)
         if dpos.shape[0] != T:
             raise RuntimeError("dpos must be the [T, C] slice of the position gradient")
-    check(lib.dg_embed_bwd(_p(idx), _p(dx), _p(dtok), _p(dpos), B, T, Cd, V, _stream()), "dg_embed_bwd")
+    check(lib.dg_embed_bwd(_p(idx), _p(dx), dt_code(dx.dtype), _p(dtok), _p(dpos), B, T, Cd, V, _stream()), "dg_embed_bwd")
 
 
 def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, out_dtype: torch.dtype, eps: float = 1e-5):
@@ -160,15 +160,19 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
 
 def layernorm_bwd_fused(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dresid: Optional[Tensor],
                         dgamma_part: Tensor, dbeta_part: Tensor, part_stride: int, n_partials: int,
-                        g_dtype: torch.dtype, p: float, rng_state: Optional[Tensor], site: int, gbias_part: Optional[Tensor]):
-    """layernorm_bwd that also emits g = dropout_bwd(dx) in g_dtype and its column-sum partials; returns (dx, g)."""
+                        g_dtype: torch.dtype, p: float, rng_state: Optional[Tensor], site: int, gbias_part: Optional[Tensor],
+                        stream_dtype: torch.dtype = torch.float32):
+    """layernorm_bwd that also emits g = dropout_bwd(dx) in g_dtype and its column-sum partials; returns (dx, g).
+    stream_dtype: type of dresid (in) and dx (out), fp32 or bf16 (the engine's bf16 gradient stream: bf16 dy and g only)."""
     _chk(dy, "dy")
     _chk(x, "x", torch.float32)
+    if dresid is not None:
+        _chk(dresid, "dresid", stream_dtype)
     Cd = x.shape[-1]
     M = x.numel() // Cd
-    dx = torch.empty_like(x)
+    dx = torch.empty(x.shape, dtype=stream_dtype, device=x.device)
     g = torch.empty(x.shape, dtype=g_dtype, device=x.device)
-    check(lib.dg_layernorm_bwd_fused(_p(dy), dt_code(dy.dtype), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dresid), _p(dx), _p(dgamma_part),
+    check(lib.dg_layernorm_bwd_fused(_p(dy), dt_code(dy.dtype), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dresid), _p(dx), dt_code(stream_dtype), _p(dgamma_part),
                                      _p(dbeta_part), part_stride, n_partials, M, Cd, _p(g), dt_code(g_dtype), float(p),
                                      _p(rng_state) if p > 0.0 else None, site, _p(gbias_part), _stream()), "dg_layernorm_bwd_fused")
     return dx, g
@@ -368,12 +372,12 @@ def colsum(A: Tensor, part: Tensor, part_stride: int, n_partials: int, N: Option
 def dropout_bwd_cast(dy: Tensor, out_dtype: Optional[torch.dtype], p: float, rng_state: Optional[Tensor], site: int,
                      relu_mask: Optional[Tensor] = None, colsum_part: Optional[Tensor] = None, part_stride: int = 0,
                      n_partials: int = 0, want_g: bool = True) -> Optional[Tensor]:
-    _chk(dy, "dy", torch.float32, contiguous=False)
+    _chk(dy, "dy", contiguous=False)          # fp32, or bf16 (the engine's gradient stream)
     M, N = dy.shape
     g = torch.empty((M, N), dtype=out_dtype, device=dy.device) if want_g else None
     if relu_mask is not None:
         _chk(relu_mask, "relu_mask", torch.float32, contiguous=False)
-    check(lib.dg_dropout_bwd_cast(_p(dy), _ld(dy), _p(g), N, dt_code(out_dtype) if want_g else DG_F32, M, N, float(p),
+    check(lib.dg_dropout_bwd_cast(_p(dy), dt_code(dy.dtype), _ld(dy), _p(g), N, dt_code(out_dtype) if want_g else DG_F32, M, N, float(p),
                                   _p(rng_state) if p > 0.0 else None, site,
                                   _p(relu_mask), _ld(relu_mask) if relu_mask is not None else 0,
                                   _p(colsum_part), part_stride, n_partials, _stream()), "dg_dropout_bwd_cast")

@@ -164,6 +164,7 @@ class Run:
     fp8_sites: Optional[dict] = None # engine only: per call site [2 x FP8_AMAX_PARTS] amax history => one-pass delayed scaling
     fp8_seed: bool = False           # engine warm-up: quantise just in time and seed the sites' history with this batch's amax
     step_word: Optional[Tensor] = None   # device {seed, step} words: the step parity selects the history slot
+    stream: torch.dtype = torch.float32  # type of the residual-branch gradient stream (engine, bf16 / fp8 modes: bf16)
 
     def p(self, p: float) -> float:
         return p if (self.rng is not None and p > 0.0) else 0.0
@@ -238,7 +239,10 @@ def _ln_tail(run: Run, dh: Tensor, x2d: Tensor, ln_w: Tensor, mean, rstd, dresid
     if emit is not None and ops.layernorm_bwd_fused_supported(ln_w.numel()):
         p, site, bias_key, N = emit
         pq = sink.vector(bias_key, N)[0] if bias_key is not None else None       # None: g only (no sub-layer bias behind it)
-        return ops.layernorm_bwd_fused(dh, x2d, ln_w, mean, rstd, dresid, pg, pb, sg, ng, run.act, run.p(p), run.rng, site, pq)
+        return ops.layernorm_bwd_fused(dh, x2d, ln_w, mean, rstd, dresid, pg, pb, sg, ng, run.act, run.p(p), run.rng, site, pq,
+                                       stream_dtype=run.stream)
+    if run.stream != torch.float32:
+        raise RuntimeError("the bf16 gradient stream needs the fused LayerNorm backward (C % 4 == 0, C <= 1024)")
     return ops.layernorm_bwd(dh, x2d, ln_w, mean, rstd, dresid, pg, pb, sg, ng), None
 
 
@@ -391,7 +395,7 @@ def linear_bwd_from_act(run: Run, saved, g: Tensor, w: Tensor, has_bias: bool, s
     Kp = k_pad(N, run.act)
     if ops._ld(g) < Kp or wt.shape[1] < Kp:                       # caller padded to the granule only
         Kp = pad_to(N, granule(run.act))
-    return ops.gemm_nt(g, wt, torch.float32, K=Kp)
+    return ops.gemm_nt(g, wt, run.stream, K=Kp)                   # the head of the gradient stream
 
 
 def linear_bwd(run: Run, saved, dy: Tensor, w: Tensor, has_bias: bool, sink, keys, need_dx: bool = True):
@@ -408,6 +412,6 @@ def linear_bwd(run: Run, saved, dy: Tensor, w: Tensor, has_bias: bool, sink, key
         # pad the contraction dim of the dX GEMM with zeros (V = 50257 is not a multiple of 8)
         gp = torch.zeros((M, Np), dtype=run.act, device=dy.device)
         g = gp[:, :N]
-        ops.check(ops.lib.dg_dropout_bwd_cast(dy.data_ptr(), ops._ld(dy), gp.data_ptr(), Np, ops.dt_code(run.act), M, N, 0.0, None, 0,
+        ops.check(ops.lib.dg_dropout_bwd_cast(dy.data_ptr(), ops.dt_code(dy.dtype), ops._ld(dy), gp.data_ptr(), Np, ops.dt_code(run.act), M, N, 0.0, None, 0,
                                               None, 0, ops._p(part), stride or 0, n or 0, ops._stream()), "dg_dropout_bwd_cast")
     return linear_bwd_from_act(run, saved, g, w, has_bias, sink, keys, need_dx, bias_done=True)

@@ -143,7 +143,7 @@ def ffn_forward(sd: SD, prefix: str, x: Tensor, p: float = 0.0, training: bool =
 
 
 def block_forward(sd: SD, prefix: str, kind: str, x: Tensor, p: float = 0.0,
-                  training: bool = False, masks: Optional[dict] = None, bf16: bool = False) -> Tensor:
+                  training: bool = False, masks: Optional[dict] = None, bf16: bool = False, stream_bf16: bool = False) -> Tensor:
     """Block (mc:179-181), ResidualBlock (mc:303-305), ResidualBlock2 (mc:505-507)."""
     if kind == "Block":
         return ffn_forward(sd, prefix + "ffwd.", mha_forward(sd, prefix + "sa_head.", x))
@@ -152,8 +152,11 @@ def block_forward(sd: SD, prefix: str, kind: str, x: Tensor, p: float = 0.0,
         return x + ffn_forward(sd, prefix + "ffwd.", x)
     if kind == "ResidualBlock2":
         C = x.shape[-1]
+        # stream_bf16 (rounding model of the engine's bf16 / fp8 modes): the gradient that arrives at the residual stream after
+        # each sub-layer is stored in bf16 (the forward stream itself stays fp32)
+        x = _rg(x, stream_bf16)
         h = _rb(F.layer_norm(x, (C,), sd[prefix + "ln1.weight"], sd[prefix + "ln1.bias"], 1e-5), bf16)
-        x = x + mha_forward(sd, prefix + "sa_head.", h, p, training, masks, bf16)
+        x = _rg(x + mha_forward(sd, prefix + "sa_head.", h, p, training, masks, bf16), stream_bf16)
         h = _rb(F.layer_norm(x, (C,), sd[prefix + "ln2.weight"], sd[prefix + "ln2.bias"], 1e-5), bf16)
         m = None if masks is None else masks.get(f"{prefix}ffwd")
         return x + ffn_forward(sd, prefix + "ffwd.", h, p, training, m, bf16)
@@ -174,8 +177,8 @@ def _num_layers(sd: SD) -> int:
 # the six LMs
 # --------------------------------------------------------------------------------------
 def lm_forward(model_name: str, sd: SD, idx: Tensor, targets: Optional[Tensor] = None,
-               p: float = 0.0, training: bool = False, masks: Optional[dict] = None, bf16: bool = False
-               ) -> Tuple[Tensor, Optional[Tensor]]:
+               p: float = 0.0, training: bool = False, masks: Optional[dict] = None, bf16: bool = False,
+               stream_bf16: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
     """forward(idx, targets) of any of the six LMs.
 
     ``bf16=True`` (TransformerLM only) is NOT the reference's arithmetic: it inserts a bf16 rounding wherever the HIP
@@ -200,8 +203,8 @@ def lm_forward(model_name: str, sd: SD, idx: Tensor, targets: Optional[Tensor] =
         else:
             kind = _BLOCK_KIND[model_name]
             for l in range(_num_layers(sd)):
-                x = block_forward(sd, f"blocks.{l}.", kind, x, p, training, masks, bf16)
-        logits = F.linear(_rb(x, bf16), _rb(sd["lm_head.weight"], bf16), sd["lm_head.bias"])   # :599
+                x = block_forward(sd, f"blocks.{l}.", kind, x, p, training, masks, bf16, stream_bf16)
+        logits = F.linear(_rb(_rg(x, stream_bf16), bf16), _rb(sd["lm_head.weight"], bf16), sd["lm_head.bias"])   # :599
     if targets is None:
         return logits, None
     B, T, V = logits.shape
@@ -370,7 +373,7 @@ class AdamWState:
 
 
 def loss_and_grads(model_name: str, sd: SD, idx: Tensor, targets: Tensor, p: float = 0.0,
-                   training: bool = False, masks: Optional[dict] = None, bf16: bool = False):
+                   training: bool = False, masks: Optional[dict] = None, bf16: bool = False, stream_bf16: bool = False):
     """logits, loss and d(loss)/d(param) for every trainable key (autograd over the
     restatement; ref: loss.backward() at src/train.py:150)."""
     keys = trainable_keys(model_name, sd)
@@ -380,7 +383,7 @@ def loss_and_grads(model_name: str, sd: SD, idx: Tensor, targets: Tensor, p: flo
         t = sd[k].detach().clone().requires_grad_(True)
         work[k] = t
         leaves.append(t)
-    logits, loss = lm_forward(model_name, work, idx, targets, p, training, masks, bf16)
+    logits, loss = lm_forward(model_name, work, idx, targets, p, training, masks, bf16, stream_bf16)
     gs = torch.autograd.grad(loss, leaves, allow_unused=True)
     grads = {k: g for k, g in zip(keys, gs)}
     return logits.detach(), loss.detach(), grads

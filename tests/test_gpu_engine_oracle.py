@@ -76,7 +76,8 @@ def test_scaled_bf16_graph_step_with_dropout_matches_oracle(dev):
         assert e_ref["logits"] < 6e-3 and e_ref["loss"] < 1e-4 and e_ref["flat"] < 1.5e-2, e_ref
         del lo, gr
         # (2) the same with the kernels' bf16 roundings: tight, per tensor
-        lo, ls, gr = R.loss_and_grads("TransformerLM", sd, x, y, p=p, training=True, masks=masks, bf16=True)
+        lo, ls, gr = R.loss_and_grads("TransformerLM", sd, x, y, p=p, training=True, masks=masks, bf16=True,
+                                      stream_bf16=eng.stream_dtype == torch.bfloat16)
         e_emu = dict(logits=rel(logits, lo), loss=abs(loss - ls.item()) / ls.item(), flat=rel(_flat(got, keys), _flat(gr, keys)))
         per = {k: rel(got[k], gr[k]) for k in keys}
         worst = max(per.items(), key=lambda kv: kv[1])

@@ -402,6 +402,53 @@ def test_layernorm_bwd_fused(dev, C, p, dy_dtype, g_dtype):
     assert rel(dx2, xd.grad) < 2e-6 and rel(g2, xd.grad) < (2e-6 if g_dtype == torch.float32 else 3e-3)
 
 
+@pytest.mark.parametrize("C", [384, 768])
+def test_layernorm_bwd_fused_bf16_gradient_stream(dev, C):
+    """the engine's bf16 / fp8 modes: dresid arrives and dx leaves in bf16 (stream_dtype): dx is the bf16 rounding of the fp32
+    result on the bf16 dresid, g and the partial rows are computed from the UNROUNDED dx"""
+    from oracle import rng_ref
+    ops = _ops()
+    M, G, site, seed, step, p = 1000, 24, 5, 11, 2, 0.2
+    gen = torch.Generator().manual_seed(C)
+    x = torch.randn(M, C, generator=gen)
+    w, b = torch.randn(C, generator=gen), torch.randn(C, generator=gen)
+    dy = torch.randn(M, C, generator=gen).bfloat16()
+    dres = torch.randn(M, C, generator=gen).bfloat16()
+    xd = x.double().requires_grad_(True)
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xd, (C,), wd, bd, 1e-5).backward(dy.double())
+    dx_ref = xd.grad + dres.double()
+    keep = torch.from_numpy(rng_ref.keep_mask(seed, step, site, p, M * C).reshape(M, C)).double()
+    g_ref = dx_ref * keep / (1.0 - p)
+    _, mean, rstd = ops.layernorm_fwd(x.to(dev), w.to(dev), b.to(dev), torch.float32)
+    pg, pb, pq = (torch.full((G, C), float("nan"), device=dev) for _ in range(3))
+    rng = ops.new_rng_state(seed, dev, step)
+    dx, gq = ops.layernorm_bwd_fused(dy.to(dev), x.to(dev), w.to(dev), mean, rstd, dres.to(dev), pg, pb, C, G, torch.bfloat16, p, rng, site, pq,
+                                     stream_dtype=torch.bfloat16)
+    assert dx.dtype == torch.bfloat16 and gq.dtype == torch.bfloat16
+    assert rel(dx, dx_ref) < 3e-3 and maxabs(dx, dx_ref.float().bfloat16()) <= 2 ** -7 * dx_ref.abs().max().item()
+    assert rel(gq, g_ref) < 3e-3 and torch.all(gq.float().cpu()[keep == 0] == 0)
+    out = torch.empty(3, C, device=dev)
+    for i, part in enumerate((pg, pb, pq)):
+        ops.reduce_partials(part, C, G, out[i], C)
+    assert rel(out[0], wd.grad) < 3e-6 and rel(out[1], bd.grad) < 3e-6 and rel(out[2], g_ref.sum(0)) < 3e-6
+    with pytest.raises(RuntimeError):          # the bf16 stream exists for the bf16 operand form only
+        ops.layernorm_bwd_fused(dy.float().to(dev), x.to(dev), w.to(dev), mean, rstd, dres.to(dev), pg, pb, C, G, torch.float32, 0.0, None, 0, None,
+                                stream_dtype=torch.bfloat16)
+    # consumers of the stream's two ends: dropout-backward of a bf16 gradient (top of the stack) and the embedding backward
+    part = torch.empty(G, C, device=dev)
+    g2 = ops.dropout_bwd_cast(dres.to(dev), torch.bfloat16, p, rng, site, colsum_part=part, part_stride=C, n_partials=G)
+    want = dres.double() * keep / (1.0 - p)
+    assert rel(g2, want) < 3e-3 and rel(part.sum(0), want.sum(0)) < 1e-5
+    B, T = 8, 125
+    idx = torch.randint(0, 50, (B, T), generator=gen).to(dev)
+    d3 = dres.to(dev).view(B, T, C)
+    dtok, dpos = torch.empty(50, C, device=dev), torch.empty(T, C, device=dev)
+    ops.embed_bwd(idx, d3, dtok, dpos)
+    ref_tok = torch.zeros(50, C, dtype=torch.float64).index_add_(0, idx.cpu().view(-1), dres.double())
+    assert rel(dpos, dres.double().view(B, T, C).sum(0)) < 1e-6 and rel(dtok, ref_tok) < 1e-5
+
+
 def test_layernorm_bwd_fused_rejects_unsupported_width(dev):
     ops = _ops()
     M, C = 64, 1028 * 2
