@@ -97,6 +97,18 @@ extern "C" int dg_embed_fwd(const int64_t* idx, const float* tok, const float* p
     return DG_OK;
 }
 
+// zero fill.  NOT hipMemsetAsync: inside a captured hipGraph the runtime's memset node (a fillBufferAligned dispatch whose
+// fill pattern lives in a runtime-owned argument buffer) filled the token-table gradient with garbage on every replay that
+// followed the load of a new code object -- e.g. the first torch `.double()` kernel of the process, launched between two steps
+// (found in round 2: 1280 of 2560 entries ~4e16 from the second replay on; tools/dbg_tok.py).  A kernel of this library
+// carries its arguments by value.
+__global__ void zero_f32_kernel(float* __restrict__ p, int64_t n) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        ((f32x4*)p)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 // token table: scatter-add rows with fp32 atomics (one dword per lane, contiguous per wave:
 // the shape the atomic units like -- microarch "Global float atomics")
 template <typename TX>
@@ -155,8 +167,12 @@ extern "C" int dg_embed_bwd(const int64_t* idx, const void* dx_v, int dx_dtype, 
     hipStream_t s = (hipStream_t)stream;
     int64_t M = (int64_t)B * T;
     if (dtok) {
-        hipError_t e = hipMemsetAsync(dtok, 0, (size_t)V * C * sizeof(float), s);
-        if (e != hipSuccess) return (int)e;
+        const int64_t nz = (int64_t)V * C;
+        if (!dg_aligned16(dtok)) return DG_ERR_ALIGN;
+        unsigned zgrid = (unsigned)((nz / 4 + 255) / 256);
+        if (zgrid < 1) zgrid = 1; if (zgrid > 4096) zgrid = 4096;
+        hipLaunchKernelGGL(zero_f32_kernel, dim3(zgrid), dim3(256), 0, s, dtok, nz);
+        DG_LAUNCH_CHECK();
         int64_t total = M * C;
         unsigned grid = (unsigned)((total + 255) / 256);
         if (grid > 8192) grid = 8192;

@@ -507,6 +507,10 @@ class TrainEngine:
                 # first block: also take dx in bf16 (no dropout, no bias behind it) -- the X operand of the token-table problem
                 dh, st["g0"] = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink, keys,
                                           g_in=g_next, emit=(0.0, 0, None, self.C))
+            elif self.stream_dtype != torch.float32:
+                # (bf16 gradient stream: the fused LayerNorm backward is the only form that writes it; its g output is unused)
+                dh, _ = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink, keys,
+                                   g_in=g_next, emit=(0.0, 0, None, self.C))
             else:
                 dh = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink, keys, g_in=g_next)
         st["dh"], st["g_next"] = dh, g_next
