@@ -50,7 +50,7 @@ def test_scaled_bf16_graph_step_with_dropout_matches_oracle(dev):
     eng = TrainEngine(m, B, T, lr=cfg["base_lr"], betas=cfg["betas"], seed=seed, use_graph=True)
     eng.keep_logits = True
     # the dispatch bench.py gets: grouped dW with the one-hot token problem, fused LN backward, colsum epilogue, sign bits
-    assert eng.grouped_dw and eng.onehot is not None and eng.last_block_act
+    assert eng.grouped_dw and eng.onehot is not None and eng.last_block_act and eng.stream_dtype == torch.bfloat16
     assert ops.layernorm_bwd_fused_supported(C) and ops.gemm_nt_colsum_rows(torch.bfloat16, B * T, 4 * C, C) > 0
     assert ops.gemm_nt_sign_bits_supported(torch.bfloat16, 4 * C, C)
     g = torch.Generator().manual_seed(3)
@@ -72,7 +72,7 @@ def test_scaled_bf16_graph_step_with_dropout_matches_oracle(dev):
         lo, ls, gr = R.loss_and_grads("TransformerLM", sd, x, y, p=p, training=True, masks=masks)
         e_ref = dict(logits=rel(logits, lo), loss=abs(loss - ls.item()) / ls.item(), flat=rel(_flat(got, keys), _flat(gr, keys)))
         _report(f"step {step} vs fp32 reference arithmetic", e_ref)
-        # measured on MI355X (round 2): logits 2.8e-3, loss 1.3e-6, flat gradient 7.0e-3 -- bounds at ~2x
+        # measured on MI355X (round 2): logits 2.8e-3, loss 1.3e-6, flat gradient 7.1e-3 (7.0e-3 with an fp32 gradient stream) -- bounds at ~2x
         assert e_ref["logits"] < 6e-3 and e_ref["loss"] < 1e-4 and e_ref["flat"] < 1.5e-2, e_ref
         del lo, gr
         # (2) the same with the kernels' bf16 roundings: tight, per tensor
@@ -83,7 +83,7 @@ def test_scaled_bf16_graph_step_with_dropout_matches_oracle(dev):
         worst = max(per.items(), key=lambda kv: kv[1])
         e_emu["worst_tensor"] = worst[1]
         _report(f"step {step} vs bf16-rounded oracle (worst {worst[0]})", e_emu)
-        # measured: logits 1.9e-3, loss 4e-7, flat 5.1e-3, worst tensor 2.3e-2 (the W1 gradients: 16384-term sums of ReLU-masked
+        # measured: logits 1.9e-3, loss 4e-7, flat 5.3e-3, worst tensor 2.3e-2 (the W1 gradients: 16384-term sums of ReLU-masked
         # products with heavy cancellation amplify the 2^-9 operand roundings; a rounding MODEL cannot reproduce the individual
         # roundings once accumulation order differs, so this is the noise floor of bf16 operands, not a modelling gap)
         assert e_emu["logits"] < 4e-3 and e_emu["loss"] < 1e-4 and e_emu["flat"] < 1e-2, e_emu

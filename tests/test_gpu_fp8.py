@@ -235,7 +235,7 @@ def test_fp8_module_path_equals_engine(dev):
     loss.backward()
     ref = {k: q.grad.detach().clone() for k, q in m.named_parameters() if q.grad is not None}
     m.zero_grad(set_to_none=True)
-    eng = TrainEngine(m, B, T, lr=0.0, weight_decay=0.0, use_graph=False)
+    eng = TrainEngine(m, B, T, lr=0.0, weight_decay=0.0, use_graph=False, grad_stream="fp32")      # as the module path keeps it
     eng.keep_logits = True
     eng.set_batch(x, y)
     l2 = eng.step().item()

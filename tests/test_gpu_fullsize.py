@@ -167,8 +167,8 @@ def test_gpt2_small_shape_engine_steps(dev):
     m.zero_grad(set_to_none=True)
     torch.cuda.empty_cache()
     # (a) fp32 logits, as the module path: the two run the same kernels on the same operands
-    eng32 = TrainEngine(m, B, T, lr=0.0, weight_decay=0.0, seed=seed, use_graph=False, logits="fp32")
-    assert not eng32.bf16_logits
+    eng32 = TrainEngine(m, B, T, lr=0.0, weight_decay=0.0, seed=seed, use_graph=False, logits="fp32", grad_stream="fp32")
+    assert not eng32.bf16_logits and eng32.stream_dtype == torch.float32
     eng32.set_batch(x, y)
     l32 = eng32.step().item()
     g32 = {k: v.detach().clone() for k, v in eng32.named_grads().items()}
@@ -183,7 +183,7 @@ def test_gpt2_small_shape_engine_steps(dev):
     # (b) the default at this vocabulary: bf16 logits overwritten in place by their gradient
     eng = TrainEngine(m, B, T, lr=cfg["base_lr"], betas=cfg["betas"], seed=seed, use_graph=True)
     assert eng.grouped_dw and eng.onehot is None          # V = 50257: the token-table gradient keeps the atomic scatter-add
-    assert eng.bf16_logits
+    assert eng.bf16_logits and eng.stream_dtype == torch.bfloat16      # the defaults at this shape
     eng.set_batch(x, y)
     l0 = eng.step().item()
     torch.cuda.synchronize()
