@@ -37,10 +37,11 @@ struct AttnP {
     int drop; float inv_keep; uint32_t thr; const uint32_t* rng; uint32_t site;
     int balance, rot_div;      // balance: 0 plain, 1 = cost-balanced item order (nblk % 4 == 0); rot_div = #CUs
     int xcd;                   // 1 = the workgroups of one (batch, head) land on one XCD (balanced order only)
-    char* tiles;               // optional: [B*NH][nblk(nblk+1)/2] tiles of 4 KB, see attn_bwd_dq_mfma_kernel
+    char* tiles;               // optional: [B*NH][nblk(nblk+1)/2] tiles, see attn_bwd_dq_mfma_kernel
+    int tiles_mode;            // 1: 4 KB tiles [32 q][P | dS] (LDS-staged); 2: 2 KB tiles, the lanes' 16 signed probabilities as they hold them
 };
 __device__ __forceinline__ int64_t attn_tile_index(const AttnP& p, int64_t bh, int qb, int kb) {
-    return (bh * (p.nblk * (p.nblk + 1) / 2) + qb * (qb + 1) / 2 + kb) * 4096;
+    return (bh * (p.nblk * (p.nblk + 1) / 2) + qb * (qb + 1) / 2 + kb) * (p.tiles_mode == 2 ? 2048 : 4096);
 }
 
 // Which 32-row block does this wave work on?  A causal block b costs b+1 tile iterations (nblk-b for the dK/dV
@@ -425,7 +426,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma2_kernel(AttnP p) {
 // Without dropout the compiler wants 208 registers for this loop (everything of a tile in flight at once); capped at 168 (three
 // workgroups per CU) it spilled 39 of them inside the loop: 56.6 us per layer against 36.4 us WITH dropout, which made a
 // dropout-0 step slower than a dropout-0.2 step.  The no-dropout variant therefore takes two workgroups per CU and no spills.
-template <bool DROP>      // dropout on the probabilities (compile-time: no per-element uniform branch)
+// TM: what the pass leaves behind for the dK/dV pass -- 0 nothing, 1 the [32 q][P | dS] tiles, 2 the signed probabilities only
+template <bool DROP, int TM>      // dropout on the probabilities (compile-time: no per-element uniform branch)
 __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block, pointers and loop bounds live in SGPRs
@@ -501,8 +503,9 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
         // [32 queries][P: 32 keys | dS: 32 keys] bf16 image, for attn_bwd_dkv_tiles_kernel: the dK/dV pass then needs no
         // score recomputation at all.  Staged through the V image (its MFMAs are done) so that the store is four full
         // 1 KB rows per instruction.
-        const bool emit = p.tiles != nullptr;
+        constexpr bool emit = TM == 1, emit2 = TM == 2;
         const bool rows_ok = q0 + TILE <= T;
+        bf16x8 p2[2];                                              // (tiles_mode 2) this lane's 16 signed probabilities
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             bf16x4 pv, dv;
@@ -518,6 +521,9 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
                 S[r] = ds;
                 pv[j] = (bf16_t)(pr * kf);
                 dv[j] = (bf16_t)ds;
+                // tiles_mode 2: only the probability travels, its sign bit says "dropped" (P >= 0 always); the dK/dV pass
+                // recomputes dP = dO V^T with four MFMAs and dS from it -- half the tile bytes, no LDS staging here
+                if (emit2) p2[g >> 1][4 * (g & 1) + j] = (bf16_t)((!rows_ok && qi >= T) ? 0.f : (kf != 0.f ? pr : -pr));
             }
             if (emit) {
                 if (!rows_ok && qi >= T) {                         // query rows past the sequence end (last, ragged block only)
@@ -538,6 +544,11 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
                 const int cc = ln + 64 * i, row = cc >> 3, ch = cc & 7;
                 *(u32x4*)(tb + cc * 16) = *(const u32x4*)(imgV + row * 128 + ((ch ^ (row & 7)) << 4));
             }
+        }
+        if (emit2) {
+            char* tb = p.tiles + attn_tile_index(p, bh, qb, kt) + ln * 32;      // 64 lanes x 32 B, contiguous
+            *(bf16x8*)tb = p2[0];
+            *(bf16x8*)(tb + 16) = p2[1];
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -727,6 +738,118 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_tiles_kernel(AttnP p) {
     store_N_acc(imgP, dV, 1.f, dKb + C, ld, k0, T, lane);
 }
 
+// =============================================================================================
+// dK/dV from the SIGNED-PROBABILITY tiles of the dQ pass (tiles_mode 2): per 32 x 32 tile the dQ pass leaves 2 KB -- every lane's 16
+// probabilities exactly as it holds them (lane = query, registers = keys), negative where the element was dropped -- instead of
+// 4 KB of P | dS staged through its LDS.  This pass (HBM-bound: 119 MB per launch at the scaled configuration with the 4 KB
+// tiles) turns a tile around in its own LDS ([32 q] rows of 80 B: the two half-waves of a column read hit disjoint banks),
+// recomputes dP = dO V^T with four MFMAs (V of its key block stays in registers; dO row fragments are read from the
+// transposed-read image) and dS = P (dP keep/(1-p) - delta) in registers, where they already are the A operands of
+// dV += Pd^T dO and dK += dS^T Q.  No exp, no hash, no scores.
+// MEASURED (round 2, one box, DG_ATTN_TILES=2 vs 1): backward pair 62.8 us vs 52.3 us per layer at T = 256, 180 vs 166 us at
+// T = 1024 -- SLOWER although it moves 55 MB less per layer: like the other attention kernels this pass is as long as its
+// longest wave's instruction stream (the key block that sees all 8 query tiles), and 16 two-byte LDS reads + ~100 VALU
+// instructions + 4 MFMAs per tile lengthen that stream more than the halved tile traffic shortens anything.  (The dQ side
+// does get leaner: no LDS staging, 0 spilled registers instead of 4.)  Kept as an A/B variant.
+#define WAVE_LDS_DKVP 10752                  // 2560 (P image) + 4096 (Q^T image) + 4096 (dO^T image)
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ptiles_kernel(AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int64_t bh; int blk; bool valid;
+    attn_item(p, wave, bh, blk, valid);
+    if (!valid) return;
+    char* imgP = smem + wave * WAVE_LDS_DKVP;       // [32 q][80 B]: 32 keys of bf16 + padding
+    char* imgQt = imgP + 2560;
+    char* imgGt = imgQt + 4096;
+    const int kb = p.balance ? p.nblk - 1 - blk : blk;
+    const int h = (int)(bh % p.NH), b = (int)(bh / p.NH);
+    const int T = p.T, C = p.NH * HD;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16_t* Qb = p.qkv + (int64_t)b * T * ld + h * HD;
+    const bf16_t* Vb = Qb + 2 * C;
+    const bf16_t* dOb = p.dout + (int64_t)b * T * C + h * HD;
+    const int k0 = kb * TILE, c = lane & 31, hh = lane >> 5;
+    bf16x8 vf[4];
+    frags_global(vf, Vb, ld, k0, T, lane);
+    f32x16 dK[2], dV[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dK[0][i] = 0.f; dK[1][i] = 0.f; dV[0][i] = 0.f; dV[1][i] = 0.f; }
+    const float* dlt = p.delta_r + bh * T;
+    const bool vec4 = (T % 4 == 0) && ((((uintptr_t)p.delta_r) & 15) == 0);
+    const float ik = p.drop ? p.inv_keep : 1.f;
+    auto load_pt = [&](u32x4 (&r)[2], int qt) {
+        const char* tb = p.tiles + attn_tile_index(p, bh, qt, kb) + lane * 32;
+        r[0] = *(const u32x4*)tb; r[1] = *(const u32x4*)(tb + 16);
+    };
+    u32x4 rp[2], rq[4], rg[4];
+    load_pt(rp, kb);
+    tile_load(rq, Qb, ld, k0, T, lane);
+    tile_load(rg, dOb, C, k0, T, lane);
+    for (int qt = kb; qt < p.nblk; ++qt) {
+        // the producer's lane (query c, half hh) held keys krow(r, hh): four runs of four consecutive keys (8 bytes each)
+        {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, rp[0]), bq = __builtin_bit_cast(bf16x8, rp[1]);
+            char* row = imgP + c * 80 + 8 * hh;
+            *(bf16x4*)(row) = __builtin_shufflevector(a, a, 0, 1, 2, 3);            // keys 4 hh + 0..3
+            *(bf16x4*)(row + 16) = __builtin_shufflevector(a, a, 4, 5, 6, 7);       // keys 8 + 4 hh ..
+            *(bf16x4*)(row + 32) = __builtin_shufflevector(bq, bq, 0, 1, 2, 3);     // keys 16 + 4 hh ..
+            *(bf16x4*)(row + 48) = __builtin_shufflevector(bq, bq, 4, 5, 6, 7);     // keys 24 + 4 hh ..
+        }
+        tile_store<true>(imgQt, rq, lane);
+        tile_store<true>(imgGt, rg, lane);
+        if (qt + 1 < p.nblk) {
+            load_pt(rp, qt + 1);
+            tile_load(rq, Qb, ld, (qt + 1) * TILE, T, lane);
+            tile_load(rg, dOb, C, (qt + 1) * TILE, T, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // dP[q, key] = sum_d dO[q, d] V[key, d]: rows q on the registers, key on the lane -- the layout the products below take
+        f32x16 dP;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dP[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 go = __builtin_bit_cast(bf16x8, *(const u32x4*)(imgGt + off_tr(lane & 31, 2 * ks + (lane >> 5))));   // row fragment of dO
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(go, vf[ks], dP, 0, 0, 0);
+        }
+        const int q0 = qt * TILE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 pf, df;
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const int g = 2 * s + g2;
+                const int qr = q0 + 8 * g + 4 * hh;                 // rows qr .. qr + 3 = registers 4 g .. 4 g + 3
+                f32x4 D4;
+                if (vec4) { const int qc = qr + 3 < T ? qr : T - 4; D4 = *(const f32x4*)(dlt + qc); }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int qc = qr + j < T ? qr + j : T - 1; D4[j] = dlt[qc]; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j;
+                    const float ps = (float)*(const bf16_t*)(imgP + (8 * g + 4 * hh + j) * 80 + 2 * c);   // P[q = krow(r, hh)][key c], signed
+                    const float pr = fabsf(ps);
+                    const float kf = (__float_as_uint(ps) >> 31) ? 0.f : ik;
+                    pf[4 * g2 + j] = (bf16_t)(pr * kf);
+                    df[4 * g2 + j] = (bf16_t)(pr * (dP[r] * kf - D4[j]));
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag_tr(imgGt, dt, s, lane), dV[dt], 0, 0, 0);
+                dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, frag_tr(imgQt, dt, s, lane), dK[dt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    bf16_t* dKb = p.dqkv + (int64_t)b * T * ld + C + h * HD;
+    store_N_acc(imgQt, dK, p.scale, dKb, ld, k0, T, lane);
+    __builtin_amdgcn_wave_barrier();
+    store_N_acc(imgQt, dV, 1.f, dKb + C, ld, k0, T, lane);
+}
+
 static void fill(AttnP& p, int B, int T, int NH, float scale, float dp, const uint32_t* rng, uint32_t site) {
     p.B = B; p.T = T; p.NH = NH; p.nblk = (T + TILE - 1) / TILE;
     p.n_items = (int64_t)B * NH * p.nblk;
@@ -781,23 +904,31 @@ int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const f
     fill(p, B, T, NH, scale, dp, rng, site);
     p.qkv = (const bf16_t*)qkv; p.out = (const bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv;
     p.lse_r = lse; p.delta = delta; p.delta_r = delta;
-    static const int tile_mode = [] { const char* e = getenv("DG_ATTN_TILES"); return e ? atoi(e) : 1; }();   // 0 = recompute in the dK/dV pass (A/B runs)
+    static const int tile_mode = [] { const char* e = getenv("DG_ATTN_TILES"); return e ? atoi(e) : 1; }();   // 1 = P | dS tiles (default), 2 = signed P tiles (measured slower), 0 = recompute in the dK/dV pass
     p.tiles = tile_mode ? (char*)tiles : nullptr;
+    p.tiles_mode = tile_mode == 1 ? 1 : 2;
     dim3 grid((unsigned)((p.n_items + 3) / 4)), block(256);
     // Without dropout the dQ pass still runs the DROP = true code with a threshold of 0 (every hash >= 0: keep everything) and
     // a keep scale of 1: bit-identical results, and 36 us per layer instead of the 48 us of the DROP = false variant (whose loop
     // the compiler schedules into 208 registers: 2 workgroups per CU; at 168 registers it spilled: 57 us).  The hash key is
     // read from any readable device words (the head of qkv): with threshold 0 its value cannot matter.  DG_ATTN_DQ_NODROP=1 restores it.
     static const int nodrop_variant = [] { const char* e = getenv("DG_ATTN_DQ_NODROP"); return e ? atoi(e) : 0; }();
-    if (p.drop) hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_DQ, s, p);
-    else if (nodrop_variant) hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, grid, block, 4 * WAVE_LDS_DQ, s, p);
+    const int tm = p.tiles ? p.tiles_mode : 0;
+#define DQ_LAUNCH(DROP_, Q_) do { \
+        if (tm == 2) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DROP_, 2>), grid, block, 4 * WAVE_LDS_DQ, s, Q_); \
+        else if (tm == 1) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DROP_, 1>), grid, block, 4 * WAVE_LDS_DQ, s, Q_); \
+        else hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DROP_, 0>), grid, block, 4 * WAVE_LDS_DQ, s, Q_); } while (0)
+    if (p.drop) DQ_LAUNCH(true, p);
+    else if (nodrop_variant) DQ_LAUNCH(false, p);
     else {
         AttnP q = p;
         q.thr = 0u; q.inv_keep = 1.f; q.rng = (const uint32_t*)qkv; q.site = 0;     // (qkv: at least 384 readable bytes)
-        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_DQ, s, q);
+        DQ_LAUNCH(true, q);
     }
+#undef DQ_LAUNCH
     DG_LAUNCH_CHECK();
-    if (p.tiles) hipLaunchKernelGGL(attn_bwd_dkv_tiles_kernel, grid, block, 4 * WAVE_LDS_DKVT, s, p);
+    if (tm == 2) hipLaunchKernelGGL(attn_bwd_dkv_ptiles_kernel, grid, block, 4 * WAVE_LDS_DKVP, s, p);
+    else if (p.tiles) hipLaunchKernelGGL(attn_bwd_dkv_tiles_kernel, grid, block, 4 * WAVE_LDS_DKVT, s, p);
     else if (p.drop) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_DKV, s, p);
     else hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<false>, grid, block, 4 * WAVE_LDS_DKV, s, p);
     DG_LAUNCH_CHECK();
