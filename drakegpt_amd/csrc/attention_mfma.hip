@@ -199,8 +199,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
     float m = -INFINITY, lsum = 0.f;
     const float sc = p.scale * LOG2E;
     const uint32_t key = DROP ? dg_site_key_dev(p.rng, p.site) : 0u;
-    // Weyl value of element (qi, key 4*hh) -- the per-register key offsets are compile-time constants
-    const uint32_t wbase = ((uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T) + 4u * hh) * DG_WEYL;
+    // Weyl value of the PAIR that holds element (qi, key 4*hh) (T is even: the element index of an even key is even) -- the
+    // per-register pair offsets are compile-time constants
+    const uint32_t wbase = (((uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T) + 4u * hh) >> 1) * DG_WEYL;
 
     u32x4 rk[4], rv[4];
     tile_load(rk, Kb, ld, 0, T, lane);
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgK, ks, lane), qf[ks], S, 0, 0, 0);
         const int k0 = kt * TILE;
-        const uint32_t wtile = wbase + (uint32_t)k0 * DG_WEYL;
+        const uint32_t wtile = wbase + (uint32_t)(k0 >> 1) * DG_WEYL;
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -237,11 +238,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
         m = mn;
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float e = __builtin_amdgcn_exp2f(S[r] - mn);
-            ps += e;
-            if (DROP) e = dg_keep_w(key, wtile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DG_WEYL, p.thr) ? e * p.inv_keep : 0.f;
-            S[r] = e;
+        for (int r = 0; r < 16; r += 2) {                   // registers r, r + 1 = adjacent keys = one hash pair
+            float e0 = __builtin_amdgcn_exp2f(S[r] - mn), e1 = __builtin_amdgcn_exp2f(S[r + 1] - mn);
+            ps += e0 + e1;
+            if (DROP) {
+                const uint32_t x = dg_hash_w(key, wtile + (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2)) * DG_WEYL);
+                e0 = dg_keep_lo(x, p.thr) ? e0 * p.inv_keep : 0.f;
+                e1 = dg_keep_hi(x, p.thr) ? e1 * p.inv_keep : 0.f;
+            }
+            S[r] = e0; S[r + 1] = e1;
         }
         lsum = lsum * alpha + ps;
 #pragma unroll
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma2_kernel(AttnP p) {
     float m = -INFINITY, lsum = 0.f;
     const float sc = p.scale * LOG2E;
     const uint32_t key = DROP ? dg_site_key_dev(p.rng, p.site) : 0u;
-    const uint32_t wbase = ((uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T) + 4u * hh) * DG_WEYL;
+    const uint32_t wbase = (((uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T) + 4u * hh) >> 1) * DG_WEYL;
 
     // cooperative loads: a [64 keys][64 d] tile is 512 chunks of 16 B per operand, two per thread
     u32x4 rk[2], rv[2];
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma2_kernel(AttnP p) {
             if (MODE != 2) Sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgK + 4096, ks, lane), qf[ks], Sb, 0, 0, 0);
         }
         const int k0 = it * 64;
-        const uint32_t wta = wbase + (uint32_t)k0 * DG_WEYL, wtb = wta + 32u * DG_WEYL;
+        const uint32_t wta = wbase + (uint32_t)(k0 >> 1) * DG_WEYL, wtb = wta + 16u * DG_WEYL;
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -372,17 +377,25 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma2_kernel(AttnP p) {
         m = mn;
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t wo = (uint32_t)((r & 3) + 8 * (r >> 2)) * DG_WEYL;
-            float ea = __builtin_amdgcn_exp2f(Sa[r] - mn);
-            ps += ea;
-            if (DROP) ea = dg_keep_w(key, wta + wo, p.thr) ? ea * p.inv_keep : 0.f;
-            Sa[r] = ea;
+        for (int r = 0; r < 16; r += 2) {
+            const uint32_t wo = (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2)) * DG_WEYL;
+            float e0 = __builtin_amdgcn_exp2f(Sa[r] - mn), e1 = __builtin_amdgcn_exp2f(Sa[r + 1] - mn);
+            ps += e0 + e1;
+            if (DROP) {
+                const uint32_t x = dg_hash_w(key, wta + wo);
+                e0 = dg_keep_lo(x, p.thr) ? e0 * p.inv_keep : 0.f;
+                e1 = dg_keep_hi(x, p.thr) ? e1 * p.inv_keep : 0.f;
+            }
+            Sa[r] = e0; Sa[r + 1] = e1;
             if (MODE != 2) {
-                float eb = __builtin_amdgcn_exp2f(Sb[r] - mn);
-                ps += eb;
-                if (DROP) eb = dg_keep_w(key, wtb + wo, p.thr) ? eb * p.inv_keep : 0.f;
-                Sb[r] = eb;
+                float f0 = __builtin_amdgcn_exp2f(Sb[r] - mn), f1 = __builtin_amdgcn_exp2f(Sb[r + 1] - mn);
+                ps += f0 + f1;
+                if (DROP) {
+                    const uint32_t x = dg_hash_w(key, wtb + wo);
+                    f0 = dg_keep_lo(x, p.thr) ? f0 * p.inv_keep : 0.f;
+                    f1 = dg_keep_hi(x, p.thr) ? f1 * p.inv_keep : 0.f;
+                }
+                Sb[r] = f0; Sb[r + 1] = f1;
             }
         }
         lsum = lsum * alpha + ps;
@@ -470,7 +483,7 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
     for (int i = 0; i < 16; ++i) { dQ[0][i] = 0.f; dQ[1][i] = 0.f; }
     const float sc = p.scale * LOG2E;
     const uint32_t key = DROP ? dg_site_key_dev(p.rng, p.site) : 0u;
-    const uint32_t wbase = ((uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T) + 4u * hh) * DG_WEYL;
+    const uint32_t wbase = (((uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T) + 4u * hh) >> 1) * DG_WEYL;      // pair of (qi, key 4 hh)
 
     u32x4 rk[4], rv[4];
     tile_load(rk, Kb, ld, 0, T, lane);
@@ -498,7 +511,7 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
             dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgV, ks, ln), gf[ks], dP, 0, 0, 0);
         }
         const int k0 = kt * TILE;
-        const uint32_t wtile = wbase + (uint32_t)k0 * DG_WEYL;
+        const uint32_t wtile = wbase + (uint32_t)(k0 >> 1) * DG_WEYL;
         // With p.tiles the (dropped-out) probabilities and dS of this 32 x 32 tile are also written out, side by side as a
         // [32 queries][P: 32 keys | dS: 32 keys] bf16 image, for attn_bwd_dkv_tiles_kernel: the dK/dV pass then needs no
         // score recomputation at all.  Staged through the V image (its MFMAs are done) so that the store is four full
@@ -509,6 +522,7 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             bf16x4 pv, dv;
+            uint32_t xh = 0u;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * g + j;
@@ -516,7 +530,10 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
                 float pr = __builtin_amdgcn_exp2f(S[r] * sc - L2);
                 if (kt == qb && kj > qi) pr = 0.f;
                 float kf = 1.f;
-                if (DROP) kf = dg_keep_w(key, wtile + (uint32_t)((r & 3) + 8 * (r >> 2)) * DG_WEYL, p.thr) ? p.inv_keep : 0.f;
+                if (DROP) {
+                    if ((j & 1) == 0) xh = dg_hash_w(key, wtile + (uint32_t)((j >> 1) + 4 * g) * DG_WEYL);     // keys j, j + 1 of this run share it
+                    kf = ((j & 1) ? dg_keep_hi(xh, p.thr) : dg_keep_lo(xh, p.thr)) ? p.inv_keep : 0.f;
+                }
                 const float ds = pr * (dP[r] * kf - dl);
                 S[r] = ds;
                 pv[j] = (bf16_t)(pr * kf);
@@ -621,8 +638,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
             dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgG, ks, lane), vf[ks], dP, 0, 0, 0);
         }
         const int q0 = qt * TILE;
-        const uint32_t wrow = (uint32_t)T * DG_WEYL;                          // one query row further
-        const uint32_t wq = (uint32_t)(((uint64_t)bh * T + q0 + 4 * hh) * (uint64_t)T + kj) * DG_WEYL;
+        const uint32_t iq = (uint32_t)(((uint64_t)bh * T + q0 + 4 * hh) * (uint64_t)T + kj);       // element index of (query q0 + 4 hh, key kj)
         f32x16 Pd;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -650,7 +666,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
                 float pr = __builtin_amdgcn_exp2f(S[r] * sc - L2);
                 if ((qt == kb && kj > qi) || !ok) pr = 0.f;
                 float keepf = 1.f;
-                if (DROP) keepf = dg_keep_w(key, wq + (uint32_t)(8 * g + j) * wrow, p.thr) ? p.inv_keep : 0.f;
+                if (DROP) keepf = dg_keep(key, iq + (uint32_t)(8 * g + j) * (uint32_t)T, p.thr) ? p.inv_keep : 0.f;   // one key per lane: no pair to share
                 Pd[r] = pr * keepf;
                 S[r] = pr * (dP[r] * keepf - dl);
             }
@@ -674,7 +690,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
 
 // =============================================================================================
 bool dg_attn_mfma_supported(int B, int T, int NH, int H) {
-    return H == HD && B > 0 && T > 0 && NH > 0 && (int64_t)B * NH * T * T < ((int64_t)1 << 32);
+    // (T even: a lane's adjacent keys then form the element pairs that share a dropout hash)
+    return H == HD && B > 0 && T > 0 && T % 2 == 0 && NH > 0 && (int64_t)B * NH * T * T < ((int64_t)1 << 32);
 }
 
 

@@ -38,27 +38,33 @@ __host__ __device__ inline uint32_t dg_site_key(uint32_t seed_lo, uint32_t seed_
 __device__ inline uint32_t dg_site_key_dev(const uint32_t* rng_state, uint32_t site) {
     return dg_site_key(rng_state[0], rng_state[1], rng_state[2], site);
 }
+// One 32-bit hash serves TWO elements (2i and 2i + 1): element idx is kept iff its 16-bit field of hash(key, idx >> 1) -- the
+// low half for even idx, the high half for odd idx -- is >= thr16 = floor(p * 65536).  The hash was 56 of the ~100 VALU
+// instructions an attention wave issues per 32-key tile, and a wave's instruction stream IS the attention kernels' run time
+// (DESIGN section 4): a lane's 16 scores are 8 adjacent-key pairs, the 8 output columns of a GEMM epilogue lane 4 pairs.
+// p is realised to 2^-16 (0.2 -> 0.19999695; torch's own bernoulli_ compares 24-bit uniforms).
 __host__ __device__ inline uint32_t dg_drop_threshold(float p) {
-    double t = (double)p * 4294967296.0;
-    if (t >= 4294967295.0) return 0xFFFFFFFFu;
+    double t = (double)p * 65536.0;
+    if (t >= 65535.0) return 0xFFFFu;
     if (t <= 0.0) return 0u;
     return (uint32_t)t;
 }
-// keep element idx?  (drop iff hash < thr).  The element hash is a Weyl step (idx * golden ratio, which
-// callers can also form incrementally with adds: dg_keep_w), one xorshift32 round and ONE multiply;
-// the comparison looks at the high bits, which depend on every input bit.  v_mul_lo_u32 is a
-// quarter-rate instruction and this hash runs once per attention probability, so it is deliberately
-// leaner than dg_mix32 (measured keep rate / lag correlations / row and column dispersion match the
-// full mixer's: oracle/rng_ref.py restates it, tests/test_host_logic.py checks the statistics).
+// The pair hash is a Weyl step ((idx >> 1) * golden ratio, which callers can also form incrementally with adds), one
+// xorshift32 round and ONE multiply (v_mul_lo_u32 is a quarter-rate instruction); both 16-bit halves of the product depend
+// on every input bit through the xorshift (measured keep rate / lag correlations / row and column dispersion / in-pair
+// correlation: oracle/rng_ref.py restates it, tests/test_host_logic.py checks the statistics).
 #define DG_WEYL 0x9E3779B1U
-__device__ __forceinline__ bool dg_keep_w(uint32_t key, uint32_t w, uint32_t thr) {     // w = idx * DG_WEYL
-    uint32_t x = key ^ w;
+__device__ __forceinline__ uint32_t dg_hash_w(uint32_t key, uint32_t w2) {               // w2 = (idx >> 1) * DG_WEYL
+    uint32_t x = key ^ w2;
     x ^= x >> 17; x ^= x << 11; x ^= x >> 13;
     x *= 0x7feb352dU;
-    return x >= thr;
+    return x;
 }
-__device__ __forceinline__ bool dg_keep(uint32_t key, uint32_t idx, uint32_t thr) {
-    return dg_keep_w(key, idx * DG_WEYL, thr);
+__device__ __forceinline__ bool dg_keep_lo(uint32_t x, uint32_t thr) { return (x & 0xFFFFu) >= thr; }   // element 2i
+__device__ __forceinline__ bool dg_keep_hi(uint32_t x, uint32_t thr) { return (x >> 16) >= thr; }       // element 2i + 1
+__device__ __forceinline__ bool dg_keep(uint32_t key, uint32_t idx, uint32_t thr) {                     // any single element
+    const uint32_t x = dg_hash_w(key, (idx >> 1) * DG_WEYL);
+    return ((idx & 1u) ? (x >> 16) : (x & 0xFFFFu)) >= thr;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -67,9 +67,9 @@ __device__ __forceinline__ void nt_epilogue(const float* stage, int row_base, in
             }
         }
         if (p.drop) {
-            const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
+            const uint32_t i0 = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
+            for (int e = 0; e < 4; ++e) v[e] = dg_keep(key, i0 + (uint32_t)e, p.thr) ? v[e] * p.inv_keep : 0.f;
         }
         if (p.residual) {
             const float* rp = p.residual + (int64_t)row * p.ldr + col;

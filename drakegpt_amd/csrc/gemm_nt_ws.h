@@ -337,9 +337,19 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                     }
                 }
                 if (e_drop) {
-                    const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
+                    const uint32_t i0 = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;       // col % 8 == 0
+                    if ((p.N & 1) == 0) {                                                     // (uniform) the lane's 8 columns are 4 whole hash pairs
+                        const uint32_t w2 = (i0 >> 1) * DG_WEYL;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
+                        for (int e = 0; e < 8; e += 2) {
+                            const uint32_t x = dg_hash_w(key, w2 + (uint32_t)(e >> 1) * DG_WEYL);
+                            v[e] = dg_keep_lo(x, p.thr) ? v[e] * p.inv_keep : 0.f;
+                            v[e + 1] = dg_keep_hi(x, p.thr) ? v[e + 1] * p.inv_keep : 0.f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = dg_keep(key, i0 + (uint32_t)e, p.thr) ? v[e] * p.inv_keep : 0.f;
+                    }
                 }
                 if (e_res) {
                     const float* rp = e_res + (int64_t)row * p.ldr + col;
@@ -435,9 +445,19 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                     for (int e = 0; e < 8; ++e) v[e] = ((bm >> e) & 1u) ? v[e] : 0.f;
                 }
                 if (e_drop) {
-                    const uint32_t wb = ((uint32_t)row * (uint32_t)p.N + (uint32_t)col) * DG_WEYL;
+                    const uint32_t i0 = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;       // col % 8 == 0
+                    if ((p.N & 1) == 0) {                                                     // (uniform) the lane's 8 columns are 4 whole hash pairs
+                        const uint32_t w2 = (i0 >> 1) * DG_WEYL;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = dg_keep_w(key, wb + (uint32_t)e * DG_WEYL, p.thr) ? v[e] * p.inv_keep : 0.f;
+                        for (int e = 0; e < 8; e += 2) {
+                            const uint32_t x = dg_hash_w(key, w2 + (uint32_t)(e >> 1) * DG_WEYL);
+                            v[e] = dg_keep_lo(x, p.thr) ? v[e] * p.inv_keep : 0.f;
+                            v[e + 1] = dg_keep_hi(x, p.thr) ? v[e + 1] * p.inv_keep : 0.f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = dg_keep(key, i0 + (uint32_t)e, p.thr) ? v[e] * p.inv_keep : 0.f;
+                    }
                 }
                 if (e_res) {
 #pragma unroll

@@ -197,9 +197,13 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
                     if (FUSE_G) {
                         f32x4 gq = o;
                         if (fz.drop) {
-                            const uint32_t wb = ((uint32_t)row * (uint32_t)C + (uint32_t)(i * 4)) * DG_WEYL;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) gq[j] = dg_keep_w(fkey, wb + (uint32_t)j * DG_WEYL, fz.thr) ? o[j] * fz.inv_keep : 0.f;
+                            // C % 4 == 0: the four elements are two whole hash pairs
+                            const uint32_t w2 = (((uint32_t)row * (uint32_t)C + (uint32_t)(i * 4)) >> 1) * DG_WEYL;
+                            const uint32_t x0 = dg_hash_w(fkey, w2), x1 = dg_hash_w(fkey, w2 + DG_WEYL);
+                            gq[0] = dg_keep_lo(x0, fz.thr) ? o[0] * fz.inv_keep : 0.f;
+                            gq[1] = dg_keep_hi(x0, fz.thr) ? o[1] * fz.inv_keep : 0.f;
+                            gq[2] = dg_keep_lo(x1, fz.thr) ? o[2] * fz.inv_keep : 0.f;
+                            gq[3] = dg_keep_hi(x1, fz.thr) ? o[3] * fz.inv_keep : 0.f;
                         }
                         gb[k] += gq;
                         if (FUSE_G == 1) {

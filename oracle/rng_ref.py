@@ -33,12 +33,12 @@ def site_key(seed: int, step: int, site: int) -> int:
 
 
 def threshold(p: float) -> int:
-    """drop iff r < thr; thr = floor(p * 2^32) clamped (dg_drop_threshold)."""
-    return min(int(p * 4294967296.0), 0xFFFFFFFF)
+    """drop iff the element's 16-bit field < thr16; thr16 = floor(p * 2^16) clamped (dg_drop_threshold)."""
+    return min(int(p * 65536.0), 0xFFFF)
 
 
 def element_hash(key: int, idx: np.ndarray) -> np.ndarray:
-    """dg_keep_w in common.h: Weyl step, one xorshift32 round, one multiply."""
+    """dg_hash_w in common.h on the PAIR index idx: Weyl step, one xorshift32 round, one multiply."""
     x = np.uint64(key) ^ ((idx.astype(np.uint64) * np.uint64(0x9E3779B1)) & _M32)
     x ^= x >> np.uint64(17)
     x ^= (x << np.uint64(11)) & _M32
@@ -47,9 +47,12 @@ def element_hash(key: int, idx: np.ndarray) -> np.ndarray:
 
 
 def keep_mask(seed: int, step: int, site: int, p: float, n: int) -> np.ndarray:
-    """keep[i] for linear element indices i in [0, n) (n < 2^32) as float32 {0,1}."""
-    r = element_hash(site_key(seed, step, site), np.arange(n, dtype=np.uint64))
-    return (r >= np.uint64(threshold(p))).astype(np.float32)
+    """keep[i] for linear element indices i in [0, n) (n < 2^32) as float32 {0,1}: elements 2j and 2j + 1 share
+    hash(key, j); the even one takes its low 16 bits, the odd one its high 16 bits (dg_keep in common.h)."""
+    idx = np.arange(n, dtype=np.uint64)
+    r = element_hash(site_key(seed, step, site), idx >> np.uint64(1))
+    field = np.where((idx & np.uint64(1)) == 1, r >> np.uint64(16), r & np.uint64(0xFFFF))
+    return (field >= np.uint64(threshold(p))).astype(np.float32)
 
 
 # site numbering shared with drakegpt_amd/functional.py

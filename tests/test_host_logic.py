@@ -120,7 +120,7 @@ def test_dropout_hash_reference_properties():
     assert not (m == rng_ref.keep_mask(1, 1, 0, 0.2, 200000)).all()      # step re-keys the stream
     assert not (m == rng_ref.keep_mask(1, 0, 1, 0.2, 200000)).all()      # site re-keys the stream
     assert (m == rng_ref.keep_mask(1, 0, 0, 0.2, 200000)).all()
-    assert rng_ref.threshold(0.0) == 0 and rng_ref.threshold(0.5) == 2 ** 31
+    assert rng_ref.threshold(0.0) == 0 and rng_ref.threshold(0.5) == 2 ** 15 and rng_ref.threshold(0.2) == 13107
     # the lean element hash behaves like independent Bernoulli draws: lag correlations ~ 1/sqrt(n),
     # row sums (256 consecutive elements = one attention row) binomially dispersed
     import numpy as np
@@ -129,6 +129,10 @@ def test_dropout_hash_reference_properties():
         assert abs(np.corrcoef(k[:-lag], k[lag:])[0, 1]) < 4e-3, lag
     rows = k.reshape(-1, 256).sum(1)
     assert 0.93 < rows.var() / (256 * 0.2 * 0.8) < 1.07
+    # two elements share one 32-bit hash (low / high 16 bits): no correlation inside a pair, columns dispersed too
+    assert abs(np.corrcoef(k[0::2], k[1::2])[0, 1]) < 4e-3
+    cols = k.reshape(-1, 256).mean(0)
+    assert 0.8 < cols.var() / (0.2 * 0.8 / 8192) < 1.25
 
 
 # ------------------------------------------------------------------------------------------------ data side
