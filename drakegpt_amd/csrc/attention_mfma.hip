@@ -484,6 +484,7 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
     const float sc = p.scale * LOG2E;
     const uint32_t key = DROP ? dg_site_key_dev(p.rng, p.site) : 0u;
     const uint32_t wbase = (((uint32_t)(((uint64_t)bh * T + qi) * (uint64_t)T) + 4u * hh) >> 1) * DG_WEYL;      // pair of (qi, key 4 hh)
+    const uint32_t zs = p.thr >> 16;               // thr <= 0xFFFF: always 0, but not to the compiler (see the hash below)
 
     u32x4 rk[4], rv[4];
     tile_load(rk, Kb, ld, 0, T, lane);
@@ -531,7 +532,12 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
                 if (kt == qb && kj > qi) pr = 0.f;
                 float kf = 1.f;
                 if (DROP) {
-                    if ((j & 1) == 0) xh = dg_hash_w(key, wtile + (uint32_t)((j >> 1) + 4 * g) * DG_WEYL);     // keys j, j + 1 of this run share it
+                    // Keys j, j + 1 of this run read the two fields of one hash word, but the word is hashed again for
+                    // each: holding it across the pair costs this kernel 43 spilled registers (measured, +3 us per
+                    // layer), so the pair saving is taken in the forward kernels only.  `zs` (a run-time zero) on
+                    // the odd key keeps the compiler from merging the two evaluations back together.
+                    const uint32_t w2 = wtile + (uint32_t)((j >> 1) + 4 * g) * DG_WEYL + ((j & 1) ? zs : 0u);
+                    xh = dg_hash_w(key, w2);
                     kf = ((j & 1) ? dg_keep_hi(xh, p.thr) : dg_keep_lo(xh, p.thr)) ? p.inv_keep : 0.f;
                 }
                 const float ds = pr * (dP[r] * kf - dl);
@@ -639,6 +645,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
         }
         const int q0 = qt * TILE;
         const uint32_t iq = (uint32_t)(((uint64_t)bh * T + q0 + 4 * hh) * (uint64_t)T + kj);       // element index of (query q0 + 4 hh, key kj)
+        const uint32_t wq = (iq >> 1) * DG_WEYL, wstep = ((uint32_t)T >> 1) * DG_WEYL, fsh = (iq & 1u) << 4;
         f32x16 Pd;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -666,7 +673,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
                 float pr = __builtin_amdgcn_exp2f(S[r] * sc - L2);
                 if ((qt == kb && kj > qi) || !ok) pr = 0.f;
                 float keepf = 1.f;
-                if (DROP) keepf = dg_keep(key, iq + (uint32_t)(8 * g + j) * (uint32_t)T, p.thr) ? p.inv_keep : 0.f;   // one key per lane: no pair to share
+                if (DROP) {
+                    // One key per lane, so no pair to share; T is even (dg_attn_mfma_supported), so the hash word
+                    // advances by T / 2 per query row and the field is fixed by the key's parity.
+                    const uint32_t x = dg_hash_w(key, wq + (uint32_t)(8 * g + j) * wstep);
+                    keepf = __builtin_amdgcn_ubfe(x, fsh, 16) >= p.thr ? p.inv_keep : 0.f;
+                }
                 Pd[r] = pr * keepf;
                 S[r] = pr * (dP[r] * keepf - dl);
             }

@@ -61,7 +61,7 @@ __device__ __forceinline__ uint32_t dg_hash_w(uint32_t key, uint32_t w2) {      
     return x;
 }
 __device__ __forceinline__ bool dg_keep_lo(uint32_t x, uint32_t thr) { return (x & 0xFFFFu) >= thr; }   // element 2i
-__device__ __forceinline__ bool dg_keep_hi(uint32_t x, uint32_t thr) { return (x >> 16) >= thr; }       // element 2i + 1
+__device__ __forceinline__ bool dg_keep_hi(uint32_t x, uint32_t thr) { return x >= (thr << 16); }       // element 2i + 1: (x >> 16) >= thr, without the shift
 __device__ __forceinline__ bool dg_keep(uint32_t key, uint32_t idx, uint32_t thr) {                     // any single element
     const uint32_t x = dg_hash_w(key, (idx >> 1) * DG_WEYL);
     return ((idx & 1u) ? (x >> 16) : (x & 0xFFFFu)) >= thr;
