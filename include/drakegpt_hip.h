@@ -21,7 +21,8 @@
  *    thread concurrently (forward runs on one, backward on the other).
  *
  * Dropout stream: a keep decision is a stateless hash of (seed, step, site, element index)
- * (csrc/common.h: dg_keep).  `rng_state` points at 4 device uint32: {seed_lo, seed_hi, step, 0};
+ * (csrc/common.h: dg_keep): elements 2i and 2i + 1 read the low / high 16 bits of one 32-bit
+ * word hash(key, i) and are kept iff that field >= floor(p * 65536).  `rng_state` points at 4 device uint32: {seed_lo, seed_hi, step, 0};
  * the step word is advanced on the device (dg_state_advance) so a captured graph replays with
  * fresh masks.  A NULL rng_state or p == 0 disables dropout (eval mode).
  */
