@@ -18,7 +18,7 @@ DG_F32 = 0
 DG_BF16 = 1
 DG_FP8_E4M3 = 2
 DG_FP8_E5M2 = 3
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class GemmNtArgs(C.Structure):
@@ -66,6 +66,7 @@ SIGNATURES = {
     "dg_state_advance": [_vp, _vp],
     "dg_batch_gather": [_vp, _i64, _vp, _vp, _vp, _i, _i, _vp],
     "dg_embed_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp],
+    "dg_batch_embed_fwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp],
     "dg_embed_bwd": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "dg_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp],
     "dg_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],

@@ -42,19 +42,46 @@ extern "C" int dg_batch_gather(const int64_t* corpus, int64_t n_corpus, const in
 
 // ---------------------------------------------------------------------------------------------
 // embeddings (ref: src/model.py:595-597)
-template <int VEC>
+// GATHER: the token ids are not read from idx but gathered from the resident corpus at this step's window offsets (get_batch
+// and the embedding in one launch): row (step - ctl[0]) of the staged offset block, clamped to its ctl[1] rows; the work item of
+// a row's first channel chunk also leaves the ids and the targets (next tokens) behind for the loss and the backward pass.
+struct BatchSrc {
+    const int64_t* corpus; int64_t n_corpus; const int64_t* offsets; const uint32_t* step_state; const uint32_t* ctl;
+    int64_t* x_ids; int64_t* y_ids; int B;
+};
+template <int VEC, bool GATHER = false>
 __global__ void embed_fwd_kernel(const int64_t* __restrict__ idx, const float* __restrict__ tok,
                                  const float* __restrict__ pos, float* __restrict__ x,
-                                 int64_t M, int T, int C, int V, bf16_t* __restrict__ onehot, int64_t ld_onehot) {
+                                 int64_t M, int T, int C, int V, bf16_t* __restrict__ onehot, int64_t ld_onehot, BatchSrc bs) {
     const int cv = C / VEC;
     int64_t total = M * cv;
+    const int64_t* off = nullptr;
+    if (GATHER) {
+        uint32_t row = 0;
+        if (bs.ctl) {
+            const uint32_t n_rows = bs.ctl[1];
+            row = bs.step_state[2] - bs.ctl[0];
+            if (row >= n_rows) row = n_rows ? n_rows - 1 : 0;
+        }
+        off = bs.offsets + (int64_t)row * bs.B;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         int64_t m = i / cv;
         int c = (int)(i % cv) * VEC;
-        int64_t v = idx[m];
-        v = v < 0 ? 0 : (v >= V ? V - 1 : v);
         int t = (int)(m % T);
+        int64_t v;
+        if (GATHER) {
+            // offsets come from randint(n - T): o + 1 <= n - 1.  Clamp anyway: never fault on bad input.
+            int64_t o = off[m / T] + t, o1 = o + 1;
+            if (o < 0) o = 0; if (o >= bs.n_corpus) o = bs.n_corpus - 1;
+            if (o1 < 0) o1 = 0; if (o1 >= bs.n_corpus) o1 = bs.n_corpus - 1;
+            v = bs.corpus[o];
+            if (c == 0) { bs.x_ids[m] = v; bs.y_ids[m] = bs.corpus[o1]; }
+        } else {
+            v = idx[m];
+        }
+        v = v < 0 ? 0 : (v >= V ? V - 1 : v);
         if (onehot) {
             // row m of the one-hot matrix, 8 columns per (m, c) work item: the dY^T X operand that turns the token-table
             // gradient into one more problem of the grouped dW GEMM (no atomics, no scatter)
@@ -88,10 +115,32 @@ extern "C" int dg_embed_fwd(const int64_t* idx, const float* tok, const float* p
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
     if (vec)
-        hipLaunchKernelGGL(embed_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, tok, pos, x, M, T, C, V, (bf16_t*)onehot, ld_onehot);
+        hipLaunchKernelGGL(embed_fwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, tok, pos, x, M, T, C, V, (bf16_t*)onehot, ld_onehot, BatchSrc{});
     else {
         if (onehot) return DG_ERR_ALIGN;
-        hipLaunchKernelGGL(embed_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, tok, pos, x, M, T, C, V, (bf16_t*)nullptr, (int64_t)0);
+        hipLaunchKernelGGL(embed_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, idx, tok, pos, x, M, T, C, V, (bf16_t*)nullptr, (int64_t)0, BatchSrc{});
+    }
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+extern "C" int dg_batch_embed_fwd(const int64_t* corpus, int64_t n_corpus, const int64_t* offsets, const uint32_t* step_state,
+                                  const uint32_t* ctl, int64_t* x_ids, int64_t* y_ids, const float* tok, const float* pos, float* x,
+                                  int B, int T, int C, int V, void* onehot, int64_t ld_onehot, void* stream) {
+    if (!corpus || !offsets || !x_ids || !y_ids || !tok || !x || B <= 0 || T <= 0 || C <= 0 || V <= 0 || n_corpus < 2) return DG_ERR_ARG;
+    if ((ctl != nullptr) != (step_state != nullptr)) return DG_ERR_ARG;
+    if (onehot && (C % 4 || ld_onehot % 8 || ld_onehot < V || (int64_t)(C / 4) * 8 < ld_onehot || !dg_aligned16(onehot))) return DG_ERR_ARG;
+    int64_t M = (int64_t)B * T;
+    bool vec = (C % 4 == 0) && dg_aligned16(tok) && dg_aligned16(x) && (!pos || dg_aligned16(pos));
+    int64_t total = vec ? M * (C / 4) : M * C;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    const BatchSrc bs{corpus, n_corpus, offsets, step_state, ctl, x_ids, y_ids, B};
+    if (vec)
+        hipLaunchKernelGGL((embed_fwd_kernel<4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const int64_t*)nullptr, tok, pos, x, M, T, C, V, (bf16_t*)onehot, ld_onehot, bs);
+    else {
+        if (onehot) return DG_ERR_ALIGN;
+        hipLaunchKernelGGL((embed_fwd_kernel<1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const int64_t*)nullptr, tok, pos, x, M, T, C, V, (bf16_t*)nullptr, (int64_t)0, bs);
     }
     DG_LAUNCH_CHECK();
     return DG_OK;

@@ -138,6 +138,8 @@ class FlatSink:
 
 
 class TrainEngine:
+    OFFSET_ROWS = 512          # rows of the staged window-offset block allocated up front (stage_offsets grows it on demand)
+
     def __init__(self, model: TransformerLM, batch_size: int, context_length: Optional[int] = None, *,
                  lr: float = 1e-3, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-2,
                  seed: int = 42, rank: int = 0, world_size: int = 1, process_group=None, use_graph: bool = True,
@@ -204,7 +206,12 @@ class TrainEngine:
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay], dtype=torch.float32, device=self.dev)
         # dropout stream differs per data-parallel rank; the step word also drives Adam's bias correction
         self.state = ops.new_rng_state(seed + 0x9E3779B97F4A7C15 * rank & 0xFFFFFFFFFFFFFFFF, self.dev, 0)
-        self.offsets = torch.zeros((self.B,), dtype=torch.int64, device=self.dev)
+        # window offsets: a staged block [rows, B] the captured step walks through by itself (row = step word - off_ctl[0],
+        # clamped to off_ctl[1] rows); set_offsets() is the one-row form (row 0, off_ctl[1] = 1)
+        self.off_block = torch.zeros((self.OFFSET_ROWS, self.B), dtype=torch.int64, device=self.dev)
+        self.offsets = self.off_block[0]
+        self.off_ctl = torch.tensor([0, 1], dtype=torch.int32, device=self.dev)
+        self._off_rows, self._off_left = 1, None
         self.x = torch.zeros((self.B, self.T), dtype=torch.int64, device=self.dev)
         self.y = torch.zeros((self.B, self.T), dtype=torch.int64, device=self.dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=self.dev)
@@ -448,13 +455,17 @@ class TrainEngine:
                     bproj=pv(f"{l}.bproj"), ln2w=pv(f"{l}.ln2w"), ln2b=pv(f"{l}.ln2b"), w1=pv(f"{l}.w1"), b1=pv(f"{l}.b1"),
                     w2=pv(f"{l}.w2"), b2=pv(f"{l}.b2"))
 
-    def _forward(self, run: S.Run, x_idx: Tensor, y_idx: Optional[Tensor], want_grad: bool):
+    def _forward(self, run: S.Run, x_idx: Tensor, y_idx: Optional[Tensor], want_grad: bool, gather: bool = False):
         B, T = x_idx.shape
         M = B * T
         p = self.p_drop
         # backward gets the token-table gradient as one more problem of the grouped dW GEMM: one-hot(idx)^T dx
         onehot = self.onehot if (want_grad and self.onehot is not None and M == self.M) else None
-        h = ops.embed_fwd(x_idx, self.param_view("tok"), self.param_view("pos"), onehot=onehot).view(M, self.C)
+        if gather:       # get_batch inside the embedding launch: ids / targets land in self.x / self.y (= x_idx / y_idx)
+            h = ops.batch_embed_fwd(self.corpus, self.off_block, self.state, self.off_ctl, x_idx, y_idx, self.param_view("tok"),
+                                    self.param_view("pos"), onehot=onehot).view(M, self.C)
+        else:
+            h = ops.embed_fwd(x_idx, self.param_view("tok"), self.param_view("pos"), onehot=onehot).view(M, self.C)
         saved = []
         for l in range(self.L):
             P = self._layer_params(l)
@@ -546,10 +557,8 @@ class TrainEngine:
 
     def _prog_fwd_bwd(self):
         """gather the batch, forward, backward, reduce the gradient partials"""
-        if self.corpus is not None:
-            ops.batch_gather(self.corpus, self.offsets, self.T, self.x, self.y)
         run = self._train_run()
-        logits, rows, ctx = self._forward(run, self.x, self.y, True)
+        logits, rows, ctx = self._forward(run, self.x, self.y, True, gather=self.corpus is not None)
         if self.keep_logits:
             self.last_logits = logits
         ops.reduce_sum(rows, 1.0 / self.M, out=self.loss)
@@ -562,10 +571,8 @@ class TrainEngine:
         st = {}
 
         def first():
-            if self.corpus is not None:
-                ops.batch_gather(self.corpus, self.offsets, self.T, self.x, self.y)
             run = self._train_run()
-            logits, rows, ctx = self._forward(run, self.x, self.y, True)
+            logits, rows, ctx = self._forward(run, self.x, self.y, True, gather=self.corpus is not None)
             if self.keep_logits:
                 self.last_logits = logits
             ops.reduce_sum(rows, 1.0 / self.M, out=self.loss)
@@ -666,12 +673,34 @@ class TrainEngine:
         self.hyper[0:1].fill_(float(lr))
 
     def set_offsets(self, ix: Tensor):
-        """window offsets of THIS rank's rows (drawn by the host CPU generator, ref: preprocessing.py:43)"""
+        """window offsets of THIS rank's rows for the next step (drawn by the host CPU generator, ref: preprocessing.py:43)"""
+        if self._off_rows != 1:
+            self.off_ctl[1:2].fill_(1)
+            self._off_rows, self._off_left = 1, None
         if ix.is_cuda:
             self.offsets.copy_(ix, non_blocking=True)      # stream-ordered device copy (range-checked where they were staged)
         else:
             self.check_offsets(ix)
-            self.offsets.copy_(ix)                         # synchronous: stage blocks of offsets in HBM instead
+            self.offsets.copy_(ix)                         # synchronous: stage blocks of offsets instead (stage_offsets)
+
+    def stage_offsets(self, block: Tensor):
+        """window offsets of the next block.shape[0] steps, [n, B] (host tensors are range-checked, device tensors are taken as
+        checked): step k after this call gathers row k by itself -- the captured step reads its row from the device-side step
+        counter, so a training loop is nothing but graph launches between two stagings"""
+        if block.dim() != 2 or block.shape[1] != self.B or block.shape[0] < 1:
+            raise ValueError(f"stage_offsets: need [n >= 1, B = {self.B}] offsets")
+        if not block.is_cuda:
+            self.check_offsets(block)
+        n = block.shape[0]
+        if n > self.off_block.shape[0]:
+            # a larger block buffer is a new address: captured graphs go (and with them the view set_offsets writes)
+            self.off_block = torch.zeros((n, self.B), dtype=torch.int64, device=self.dev)
+            self.offsets = self.off_block[0]
+            self._graphs = None
+        self.off_block[:n].copy_(block, non_blocking=block.is_cuda)
+        self.off_ctl[0:1].copy_(self.state[2:3])          # device-side: row = step word - step word now
+        self.off_ctl[1:2].fill_(n)
+        self._off_rows, self._off_left = n, n
 
     def check_offsets(self, ix: Tensor):
         """window offsets must leave room for T + 1 tokens (ref: randint(len(data) - context_length), src/preprocessing.py:43);
@@ -690,6 +719,10 @@ class TrainEngine:
 
     def step(self) -> Tensor:
         """one training iteration on the current offsets / batch; returns the device loss scalar"""
+        if self._off_left is not None:
+            if self._off_left <= 0:
+                raise RuntimeError(f"step(): the {self._off_rows} staged offset rows are used up; stage_offsets() or set_offsets() first")
+            self._off_left -= 1
         if not self.use_graph:
             if self._dp() and self.dp_buckets > 1:
                 segs, ranges = self._prog_segments()

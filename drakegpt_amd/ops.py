@@ -112,6 +112,33 @@ def embed_fwd(idx: Tensor, tok: Tensor, pos: Optional[Tensor], out: Optional[Ten
     return out
 
 
+def batch_embed_fwd(corpus: Tensor, offsets: Tensor, step_state: Optional[Tensor], ctl: Optional[Tensor], x_ids: Tensor, y_ids: Tensor,
+                    tok: Tensor, pos: Optional[Tensor], onehot: Optional[Tensor] = None) -> Tensor:
+    """get_batch + embedding in one launch: gathers row (step - ctl[0]) of the staged offset block [n_rows, B] from the resident
+    corpus, writes the ids / targets into x_ids / y_ids [B, T] and returns x = tok[ids] + pos  [B, T, C]"""
+    _chk(corpus, "corpus", torch.int64)
+    _chk(offsets, "offsets", torch.int64)
+    _chk(x_ids, "x_ids", torch.int64)
+    _chk(y_ids, "y_ids", torch.int64)
+    _chk(tok, "tok", torch.float32)
+    B, T = x_ids.shape
+    V, Cd = tok.shape
+    if offsets.dim() != 2 or offsets.shape[1] != B or y_ids.shape != x_ids.shape:
+        raise ValueError("batch_embed_fwd: offsets must be [n_rows, B] and y_ids shaped like x_ids")
+    if (ctl is None) != (step_state is None):
+        raise ValueError("batch_embed_fwd: ctl and step_state go together")
+    if pos is not None:
+        _chk(pos, "pos", torch.float32)
+        if T > pos.shape[0]:
+            raise IndexError(f"index out of range in self: sequence length {T} exceeds context_length {pos.shape[0]}")
+    out = torch.empty((B, T, Cd), dtype=torch.float32, device=tok.device)
+    if onehot is not None:
+        _chk(onehot, "onehot", torch.bfloat16, contiguous=False)
+    check(lib.dg_batch_embed_fwd(_p(corpus), corpus.numel(), _p(offsets), _p(step_state), _p(ctl), _p(x_ids), _p(y_ids), _p(tok), _p(pos),
+                                 _p(out), B, T, Cd, V, _p(onehot), _ld(onehot) if onehot is not None else 0, _stream()), "dg_batch_embed_fwd")
+    return out
+
+
 def embed_bwd(idx: Tensor, dx: Tensor, dtok: Optional[Tensor], dpos: Optional[Tensor], V: Optional[int] = None) -> None:
     _chk(idx, "idx", torch.int64)
     _chk(dx, "dx")                         # fp32, or the engine's bf16 gradient stream

@@ -99,17 +99,14 @@ def engine_loop(engine, n_train: int, T: int, B: int, rank: int, world: int, ite
     """The training iterations of ref: src/train.py:141-172 on the engine path.  The reference draws one randint(len(data) - T,
     (B,)) per step from the global CPU generator and, every eval_interval steps, 2 * eval_iters more inside evaluate_loss --
     the SAME generator.  Here the offsets of all steps up to the next evaluation are drawn in one go (same draws, same order:
-    a stage never crosses an evaluation) and uploaded once, so a step is one 8*B-byte device copy + one graph launch.
+    a stage never crosses an evaluation) and staged in HBM once (TrainEngine.stage_offsets): the captured step finds its own row
+    through the device-side step counter, so a step is one graph launch and nothing else.
     `on_eval(it)` runs after step `it` when (it + 1) % eval_interval == 0."""
-    staged = None
     for it in range(iters):
-        at = it % eval_interval
-        if at == 0:
+        if it % eval_interval == 0:
             n = min(eval_interval, iters - it)
-            staged = torch.stack([ddist.shard_rows(draw_offsets(n_train, T, B * world, generator), rank, world) for _ in range(n)])
-            engine.check_offsets(staged)
-            staged = staged.to(device)
-        engine.set_offsets(staged[at])
+            engine.stage_offsets(torch.stack([ddist.shard_rows(draw_offsets(n_train, T, B * world, generator), rank, world)
+                                              for _ in range(n)]))
         engine.step()
         if (it + 1) % eval_interval == 0:
             on_eval(it)

@@ -45,7 +45,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 9   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 10   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -69,8 +69,16 @@ int dg_batch_gather(const int64_t* corpus, int64_t n_corpus, const int64_t* offs
 int dg_embed_fwd(const int64_t* idx, const float* tok, const float* pos, float* x,
                  int B, int T, int C, int V, void* onehot, int64_t ld_onehot, void* stream);
 /* onehot (nullable): bf16 [B*T, ld_onehot >= V, multiple of 8], row m = e_{idx[m]}.  With it the token-table gradient
- * is dg_gemm_tn_grouped problem (A = onehot, B = bf16 dx): deterministic, no atomics.
- * Backward of the above (embedding_dense_backward).  dtok [V,C] (nullable) is zero-filled here and then
+ * is dg_gemm_tn_grouped problem (A = onehot, B = bf16 dx): deterministic, no atomics. */
+/* get_batch and the embedding in ONE launch (ref: src/preprocessing.py:43-45 + src/model.py:595-597): the ids are gathered
+ * from the resident corpus at this step's window offsets and x_ids / y_ids [B, T] (the batch and its targets) are written
+ * beside x.  `offsets` is a staged block [n_rows, B] of host-drawn offsets; the row is step_state[2] - ctl[0], clamped to
+ * ctl[1] rows (ctl: 2 device uint32 {step word at staging time, n_rows}; step_state as in the header comment), so a captured
+ * step walks through the block without any per-step host copy.  ctl == step_state == NULL: row 0. */
+int dg_batch_embed_fwd(const int64_t* corpus, int64_t n_corpus, const int64_t* offsets, const uint32_t* step_state,
+                       const uint32_t* ctl, int64_t* x_ids, int64_t* y_ids, const float* tok, const float* pos, float* x,
+                       int B, int T, int C, int V, void* onehot, int64_t ld_onehot, void* stream);
+/* Backward of dg_embed_fwd (embedding_dense_backward).  dtok [V,C] (nullable) is zero-filled here and then
  * accumulated with fp32 atomics; dpos [T,C] (nullable) is overwritten with sum over b. */
 int dg_embed_bwd(const int64_t* idx, const void* dx, int dx_dtype, float* dtok, float* dpos,
                  int B, int T, int C, int V, void* stream);

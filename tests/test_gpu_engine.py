@@ -123,6 +123,47 @@ def test_corpus_gather_path(dev, golden_dir):
     assert torch.equal(eng.x.cpu(), x) and torch.equal(eng.y.cpu(), y)
 
 
+def test_staged_offsets_walk_equals_per_step_offsets(dev, golden_dir):
+    """stage_offsets: the captured step picks row (step word - word at staging) of the block by itself; the batches, losses
+    and parameters are those of set_offsets before every step (get_batch, ref: src/preprocessing.py:43-45), across two stagings
+    and a switch back to the one-row form; a used-up block raises instead of silently reusing its last row"""
+    from oracle import drake_ref as R
+    from drakegpt_amd.engine import TrainEngine
+    data = torch.randint(0, V, (5000,), generator=torch.Generator().manual_seed(42))
+    offs = torch.stack([torch.randint(len(data) - 8, (32,), generator=torch.Generator().manual_seed(50 + i)) for i in range(7)])
+    res = []
+    for staged in (False, True):
+        m, eng, fix = _mk(dev, golden_dir)
+        eng.set_corpus(data)
+        losses, xs = [], []
+        for i in range(7):
+            if not staged or i == 6:
+                eng.set_offsets(offs[i].to(dev) if i % 2 else offs[i])
+            elif i in (0, 4):
+                eng.stage_offsets(offs[0:4] if i == 0 else offs[4:6].to(dev))
+            losses.append(eng.step().item())
+            xs.append(eng.x.cpu().clone())
+            if i == 5 and staged:
+                with pytest.raises(RuntimeError, match="used up"):
+                    eng.step()
+        res.append((losses, xs, eng.flat.clone()))
+    # (this tiny fp32 model takes the atomic token scatter-add: two runs agree to fp32 summation order, not bit for bit)
+    assert res[0][0] == pytest.approx(res[1][0], rel=1e-5)
+    assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1])) and torch.allclose(res[0][2], res[1][2], rtol=1e-4, atol=1e-6)
+    for i in range(7):
+        x, _ = R.get_batch(data, 8, 32, torch.Generator().manual_seed(50 + i))
+        assert torch.equal(res[1][1][i], x)
+    with pytest.raises(IndexError, match="do not fit"):
+        eng.stage_offsets(torch.full((2, 32), len(data) - 8))
+    with pytest.raises(ValueError, match="stage_offsets"):
+        eng.stage_offsets(offs[0])
+    big = torch.randint(len(data) - 8, (TrainEngine.OFFSET_ROWS + 3, 32), generator=torch.Generator().manual_seed(9))
+    eng.stage_offsets(big)                                    # grows the block (new address: the step is captured again)
+    for i in range(3):
+        eng.step()
+    assert torch.equal(eng.x.cpu(), torch.stack([data[o:o + 8] for o in big[2].tolist()]))
+
+
 @pytest.mark.parametrize("name", ["BigramLM", "TransformerLM"])
 def test_module_path_with_hip_adamw_matches_reference_trajectory(dev, golden_dir, name):
     """the drop-in loop of src/train.py:146-151 (forward, zero_grad, backward, step) on the autograd path"""

@@ -652,6 +652,32 @@ def test_batch_gather_and_softmax(dev):
     assert rel(pr, logits[:, -1, :].double().softmax(-1)) < 1e-6
 
 
+def test_batch_embed_fwd_is_gather_plus_embedding(dev):
+    """get_batch + embedding in one launch (ref: src/preprocessing.py:43-45, src/model.py:595-597): the row of the staged
+    offset block comes from the step word, clamped to the block; ids, targets, stream and one-hot rows as the two kernels give them"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    B, T, C, V = 6, 8, 64, 80                       # (the one-hot rows are written by the C / 4 work items of a row, 8 columns each)
+    data = torch.randint(0, V, (3000,), generator=g)
+    block = torch.randint(3000 - T, (5, B), generator=g)
+    tok, pos = torch.randn(V, C, generator=g), torch.randn(T, C, generator=g)
+    for step, base, n_rows, want_row in ((7, 7, 5, 0), (9, 7, 5, 2), (11, 7, 5, 4), (40, 7, 5, 4), (3, 7, 5, 4), (9, 7, 2, 1), (None, None, 5, 0)):
+        st = ops.new_rng_state(123, dev, step) if step is not None else None
+        ctl = torch.tensor([base, n_rows], dtype=torch.int32, device=dev) if step is not None else None
+        x_ids = torch.full((B, T), -1, dtype=torch.int64, device=dev)
+        y_ids = torch.full((B, T), -1, dtype=torch.int64, device=dev)
+        onehot = torch.full((B * T, 88), 7.0, dtype=torch.bfloat16, device=dev)
+        out = ops.batch_embed_fwd(data.to(dev), block.to(dev), st, ctl, x_ids, y_ids, tok.to(dev), pos.to(dev), onehot=onehot)
+        off = block[want_row]
+        xs = torch.stack([data[i:i + T] for i in off]); ys = torch.stack([data[i + 1:i + T + 1] for i in off])
+        assert torch.equal(x_ids.cpu(), xs) and torch.equal(y_ids.cpu(), ys), (step, base, n_rows)
+        assert torch.equal(out.cpu(), tok[xs] + pos)
+        oh = torch.zeros(B * T, 88); oh[torch.arange(B * T), xs.reshape(-1)] = 1.0
+        assert torch.equal(onehot.float().cpu(), oh)
+    with pytest.raises(ValueError):
+        ops.batch_embed_fwd(data.to(dev), block[0].to(dev), None, None, x_ids, y_ids, tok.to(dev), pos.to(dev))
+
+
 def test_transpose_cast_batched(dev):
     ops = _ops()
     g = torch.Generator().manual_seed(4)

@@ -180,16 +180,16 @@ def test_staged_offsets_equal_the_reference_draw_order(iters, interval, world):
 
     class FakeEngine:
         def __init__(self, rank):
-            self.rank, self.seen = rank, []
+            self.rank, self.seen, self.block, self.at = rank, [], None, 0
 
-        def check_offsets(self, ix):
-            assert ix.min() >= 0 and ix.max() + T + 1 <= n_train
-
-        def set_offsets(self, ix):
-            self.seen.append(ix.clone())
+        def stage_offsets(self, block):             # what TrainEngine.stage_offsets promises: step k takes row k of the block
+            assert block.dim() == 2 and block.shape[1] == B
+            assert block.min() >= 0 and block.max() + T + 1 <= n_train
+            self.block, self.at = block.clone(), 0
 
         def step(self):
-            pass
+            self.seen.append(self.block[self.at])
+            self.at += 1
 
     def eval_draws(gen, sink):
         for _ in range(2 * eval_iters):                               # train, then val: evaluate_loss's draws
