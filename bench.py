@@ -325,7 +325,7 @@ def kernel_roofline(eng, offsets, peak_tflops):
         # logits in, dlogits out
         "cross_entropy": wrap("cross_entropy", lambda r, logits, tg, V, dlogits=None, **k: logits.shape[0] * V * 4 + (dlogits.numel() * esz(dlogits) if dlogits is not None else 0)),
         # p, g, m, v read; p, m, v (+ bf16 shadow) written
-        "adamw_step": wrap("adamw_step", lambda r, p, g, m, v, hy, st, gs=1.0, shadow_bf16=None, n=None: (n or p.numel()) * (28 + (2 if shadow_bf16 is not None else 0))),
+        "adamw_step": wrap("adamw_step", lambda r, p, g, m, v, hy, st, gs=1.0, shadow_bf16=None, n=None, advance=False: (n or p.numel()) * (28 + (2 if shadow_bf16 is not None else 0))),
         "embed_fwd": wrap("embed_fwd", lambda r, idx, tok, pos, out=None, onehot=None: r.numel() * 4 + idx.numel() * 8 + (onehot.numel() * 2 if onehot is not None else 0)),
         "embed_bwd": wrap("embed_bwd", lambda r, idx, dx, dtok, dpos, V=None: dx.numel() * 4 + (dpos.numel() * 4 if dpos is not None else 0) + (dtok.numel() * 4 if dtok is not None else 0)),
         "batch_gather": wrap("batch_gather", lambda r, corpus, offsets, T, x=None, y=None: offsets.numel() * T * 32),

@@ -93,9 +93,10 @@ SIGNATURES = {
     "dg_attn_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
     "dg_attn_decode": [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dg_cross_entropy": [_vp, _i, _i64, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _i, _vp],
+    "dg_cross_entropy_fused": [_vp, _i64, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp, _i64, _i, _vp, _vp, _vp, _f, _vp],
     "dg_reduce_sum": [_vp, _i64, _f, _vp, _vp],
     "dg_softmax_rows": [_vp, _i64, _vp, _i64, _i, _i, _vp],
-    "dg_adamw_step": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp],
+    "dg_adamw_step": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f, _vp, _i, _vp],
 }
 
 

@@ -77,6 +77,101 @@ __global__ __launch_bounds__(256) void cross_entropy_small_kernel(const float* _
     }
 }
 
+// The same rows-in-registers scheme as a whole loss head for the engine's step (V <= 128): workgroup b takes rows
+// [b * rows_per, (b + 1) * rows_per), writes the gradient rows, partial row b of the column sums of the gradient (the lm_head
+// bias gradient, fp32 values before rounding, row groups added in a fixed order) and its share of the loss; the workgroup that
+// arrives last at the counter adds the shares up in index order and writes loss_out = scale * sum -- the mean loss without a
+// reduction launch, bit-identical from run to run.  Shares and counter travel as agent-scope atomics (the per-XCD L2s are not
+// coherent); the counter is back at zero when the launch ends.
+struct CeFuse {
+    float* colsum_part; int64_t part_stride; int rows_per;
+    float* loss_part; unsigned* counter; float* loss_out; float loss_scale;
+};
+#define CEF_THREADS 1024                  // 64 row groups of 16 lanes: a 64-row share of the batch is in flight at once
+#define CEF_RG (CEF_THREADS / 16)
+template <typename TD>
+__global__ __launch_bounds__(CEF_THREADS) void cross_entropy_small_fused_kernel(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ targets,
+                                                                        float* __restrict__ loss_rows, TD* __restrict__ dlogits, int64_t ldd,
+                                                                        float grad_scale, int M, int V, CeFuse fz) {
+    __shared__ float red[CEF_RG][128];
+    __shared__ float lred[CEF_RG];
+    __shared__ unsigned last_flag;
+    const int tid = threadIdx.x, sub = tid & 15, rg = tid >> 4;
+    const int m_begin = blockIdx.x * fz.rows_per;
+    int m_end = m_begin + fz.rows_per; if (m_end > M) m_end = M;
+    float cacc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cacc[k] = 0.f;
+    float lsum = 0.f;
+    for (int r0 = m_begin; r0 < m_end; r0 += CEF_RG) {            // (uniform trip count: the shuffles below need every lane)
+        const int row = r0 + rg;
+        const bool ok = row < m_end;
+        const float* x = logits + (int64_t)(ok ? row : m_begin) * ldl;
+        float v[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = sub + 16 * k;
+            v[k] = i < V ? x[i] : -INFINITY;
+            mx = fmaxf(mx, v[k]);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = expf(v[k] - mx); s += v[k]; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (!ok) continue;
+        int64_t t = targets[row];
+        t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+        const float lr = mx + logf(s) - x[t];
+        if (sub == 0) { loss_rows[row] = lr; lsum += lr; }
+        TD* d = dlogits + (int64_t)row * ldd;
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = sub + 16 * k;
+            const float gk = i < V ? (v[k] * inv - (i == (int)t ? 1.f : 0.f)) * grad_scale : 0.f;
+            cacc[k] += gk;
+            if (i < (int)ldd) d[i] = from_f32<TD>(gk);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[rg][sub + 16 * k] = cacc[k];
+    if (sub == 0) lred[rg] = lsum;
+    __syncthreads();
+    if (fz.colsum_part && tid < V) {
+        float c = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < CEF_RG; ++r) c += red[r][tid];
+        fz.colsum_part[(int64_t)blockIdx.x * fz.part_stride + tid] = c;
+    }
+    if (!fz.loss_out) return;
+    if (tid == 0) {
+        float b = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < CEF_RG; ++r) b += lred[r];
+        __hip_atomic_store(fz.loss_part + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the share has left this wave before the counter moves
+        const unsigned prev = __hip_atomic_fetch_add(fz.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = prev == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // the last workgroup: every share is in memory; thread i fetches shares i, i + 256, ...; added up in index order
+    float* sh = &red[0][0];                                              // >= 2048 floats
+    for (int i = tid; i < (int)gridDim.x; i += CEF_THREADS) sh[i] = __hip_atomic_load(fz.loss_part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < (int)gridDim.x; ++i) tot += sh[i];
+        fz.loss_out[0] = tot * fz.loss_scale;
+        __hip_atomic_store(fz.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 #define CE_BLOCK 1024
 #define CE_MAXK 52                    // values per thread (128-VGPR budget at 16 waves per workgroup): rows up to 53248 logits
 // TL: logits type.  bf16 logits (the engine at the GPT-2 vocabulary: 0.82 GB instead of 1.65 GB written by lm_head and read here)
@@ -251,6 +346,26 @@ extern "C" int dg_cross_entropy(const void* logits_v, int logits_dtype, int64_t 
         hipLaunchKernelGGL(cross_entropy_kernel<bf16_t>, grid, block, 0, s, logits, ldl, targets, loss_rows, (bf16_t*)dlogits, ldd, grad_scale, grad_scale_dev, M, V);
     else if (dtype == DG_F32)
         hipLaunchKernelGGL(cross_entropy_kernel<float>, grid, block, 0, s, logits, ldl, targets, loss_rows, (float*)dlogits, ldd, grad_scale, grad_scale_dev, M, V);
+    else return DG_ERR_DTYPE;
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+
+extern "C" int dg_cross_entropy_fused(const float* logits, int64_t ldl, const int64_t* targets, float* loss_rows, void* dlogits, int64_t ldd,
+                                      int dtype, float grad_scale, int M, int V, float* colsum_part, int64_t part_stride, int n_partials,
+                                      float* loss_part, uint32_t* loss_counter, float* loss_out, float loss_scale, void* stream) {
+    if (!logits || !targets || !loss_rows || !dlogits || M <= 0 || V <= 0 || ldl < V || ldd < V) return DG_ERR_ARG;
+    if (ldd > 128 || n_partials <= 0 || n_partials > 2048) return DG_ERR_ARG;         // rows in registers; shares summed out of 8 KB of LDS
+    if (colsum_part && part_stride < V) return DG_ERR_ARG;
+    if ((loss_out != nullptr) != (loss_part != nullptr) || (loss_out != nullptr) != (loss_counter != nullptr)) return DG_ERR_ARG;
+    const int rows_per = (M + n_partials - 1) / n_partials;
+    const CeFuse fz{colsum_part, part_stride, rows_per, loss_part, (unsigned*)loss_counter, loss_out, loss_scale};
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DG_BF16)
+        hipLaunchKernelGGL(cross_entropy_small_fused_kernel<bf16_t>, dim3(n_partials), dim3(CEF_THREADS), 0, s, logits, ldl, targets, loss_rows, (bf16_t*)dlogits, ldd, grad_scale, M, V, fz);
+    else if (dtype == DG_F32)
+        hipLaunchKernelGGL(cross_entropy_small_fused_kernel<float>, dim3(n_partials), dim3(CEF_THREADS), 0, s, logits, ldl, targets, loss_rows, (float*)dlogits, ldd, grad_scale, M, V, fz);
     else return DG_ERR_DTYPE;
     DG_LAUNCH_CHECK();
     return DG_OK;

@@ -770,12 +770,16 @@ extern "C" int dg_softmax_rows(const float* logits, int64_t ldl, float* probs, i
 // ---------------------------------------------------------------------------------------------
 // AdamW over a flat buffer (ref: src/train.py:121,151).  16 B/lane streams: reads p,g,m,v and
 // writes p,m,v = 28 B/param (+2 B for the bf16 shadow).
+// advance: the step word moves on inside this launch -- every workgroup reads it first thing and registers at an arrival
+// counter (word 3 of the state) when it is done; the last one to arrive writes step + 1 and clears the counter.  (A separate
+// one-thread launch for that cost 4 us of the step.)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, int64_t n, const float* __restrict__ hyper,
-                             const uint32_t* __restrict__ rng_state, float grad_scale,
-                             bf16_t* __restrict__ shadow) {
+                             uint32_t* rng_state, float grad_scale,
+                             bf16_t* __restrict__ shadow, int advance) {
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
-    const float t = (float)(rng_state[2] + 1u);
+    const uint32_t step_now = rng_state[2];
+    const float t = (float)(step_now + 1u);
     const float bc1 = 1.f - powf(b1, t);
     const float bc2 = 1.f - powf(b2, t);
     const float step_size = lr / bc1;
@@ -818,16 +822,26 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
         p[i] = pj; m[i] = mj; v[i] = vj;
         if (shadow) shadow[i] = (bf16_t)pj;
     }
+    if (advance) {
+        __syncthreads();                                   // (every wave of this workgroup has read the step word long ago)
+        if (threadIdx.x == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(rng_state + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == gridDim.x - 1) {
+                __hip_atomic_store(rng_state + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(rng_state + 2, step_now + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 extern "C" int dg_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
-                             const uint32_t* rng_state, float grad_scale, void* shadow_bf16, void* stream) {
+                             uint32_t* rng_state, float grad_scale, void* shadow_bf16, int advance_step, void* stream) {
     if (!p || !g || !m || !v || !hyper || !rng_state || n <= 0) return DG_ERR_ARG;
     if (!dg_aligned16(p) || !dg_aligned16(g) || !dg_aligned16(m) || !dg_aligned16(v)) return DG_ERR_ALIGN;
     unsigned grid = (unsigned)((n / 4 + 255) / 256);
     if (grid == 0) grid = 1;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper, rng_state, grad_scale, (bf16_t*)shadow_bf16);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper, rng_state, grad_scale, (bf16_t*)shadow_bf16, advance_step);
     DG_LAUNCH_CHECK();
     return DG_OK;
 }

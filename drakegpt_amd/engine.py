@@ -215,6 +215,7 @@ class TrainEngine:
         self.x = torch.zeros((self.B, self.T), dtype=torch.int64, device=self.dev)
         self.y = torch.zeros((self.B, self.T), dtype=torch.int64, device=self.dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=self.dev)
+        self.loss_scratch = torch.zeros((2048 + 1,), dtype=torch.float32, device=self.dev)     # fused loss head: shares + arrival counter
         self.corpus: Optional[Tensor] = None
         self._graphs = None
         self._eval_graph = None
@@ -488,13 +489,21 @@ class TrainEngine:
         dlogits = None
         if want_grad:
             dlogits = torch.empty((M, S.k_pad(self.V, self.act)), dtype=self.act, device=self.dev)
+            if M == self.M and ops.cross_entropy_fused_supported(logits, dlogits, self.G):
+                # small vocabulary: the loss head in one launch -- gradient rows, the lm_head bias partials and the mean loss
+                part, stride, n = FlatSink(self).vector("lm.b", self.V)
+                rows = ops.cross_entropy_fused(logits, y_idx.view(M), self.V, dlogits, 1.0 / M, part, stride, n, self.loss_scratch,
+                                               self.loss, 1.0 / M)
+                return logits, rows, (saved, xa, dlogits, True)
         rows = ops.cross_entropy(logits, y_idx.view(M), self.V, dlogits=dlogits, grad_scale=1.0 / M)
         return logits, rows, (saved, xa, dlogits)
 
     def _backward_begin(self, run: S.Run, x_idx: Tensor, ctx) -> dict:
-        saved, xa, dlogits = ctx
+        saved, xa, dlogits = ctx[:3]
+        head_done = len(ctx) > 3            # the fused loss head already left the lm_head bias partials (and the loss) behind
         st = dict(run=run, x_idx=x_idx, saved=saved, sink=FlatSink(self), g_next=None, g0=None)
-        st["dh"] = S.linear_bwd_from_act(run, (xa,), dlogits[:, :self.V], self.param_view("lm.w"), True, st["sink"], {"w": "lm.w", "b": "lm.b"})
+        st["dh"] = S.linear_bwd_from_act(run, (xa,), dlogits[:, :self.V], self.param_view("lm.w"), True, st["sink"], {"w": "lm.w", "b": "lm.b"},
+                                         bias_done=head_done)
         return st
 
     def _backward_layers(self, st: dict, layers) -> None:
@@ -561,7 +570,8 @@ class TrainEngine:
         logits, rows, ctx = self._forward(run, self.x, self.y, True, gather=self.corpus is not None)
         if self.keep_logits:
             self.last_logits = logits
-        ops.reduce_sum(rows, 1.0 / self.M, out=self.loss)
+        if len(ctx) == 3:
+            ops.reduce_sum(rows, 1.0 / self.M, out=self.loss)
         self._backward(run, self.x, ctx)
 
     def _prog_segments(self):
@@ -575,7 +585,8 @@ class TrainEngine:
             logits, rows, ctx = self._forward(run, self.x, self.y, True, gather=self.corpus is not None)
             if self.keep_logits:
                 self.last_logits = logits
-            ops.reduce_sum(rows, 1.0 / self.M, out=self.loss)
+            if len(ctx) == 3:
+                ops.reduce_sum(rows, 1.0 / self.M, out=self.loss)
             st.clear()
             st.update(self._backward_begin(run, self.x, ctx))
 
@@ -594,10 +605,10 @@ class TrainEngine:
         return segs, [r for _, r in plan]
 
     def _prog_update(self):
+        # (the step word moves on inside the AdamW launch: nothing after it reads the word)
         ops.adamw_step(self.flat, self.gflat, self.m_, self.v_, self.hyper, self.state, 1.0 / self.world,
-                       shadow_bf16=self.shadow, n=self.n_active)
+                       shadow_bf16=self.shadow, n=self.n_active, advance=True)
         self._refresh_transposes()
-        ops.state_advance(self.state)
 
     def _dp(self) -> bool:
         return self.world > 1 or self.force_dp_path

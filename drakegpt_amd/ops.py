@@ -502,6 +502,38 @@ def cross_entropy(logits: Tensor, targets: Tensor, V: int, dlogits: Optional[Ten
     return loss_rows
 
 
+def cross_entropy_fused_supported(logits: Tensor, dlogits: Tensor, n_partials: int) -> bool:
+    return logits.dtype == torch.float32 and _ld(dlogits) <= 128 and 0 < n_partials <= 2048
+
+
+def cross_entropy_fused(logits: Tensor, targets: Tensor, V: int, dlogits: Tensor, grad_scale: float, colsum_part: Optional[Tensor],
+                        part_stride: int, n_partials: int, loss_scratch: Optional[Tensor], loss_out: Optional[Tensor], loss_scale: float,
+                        loss_rows: Optional[Tensor] = None) -> Tensor:
+    """cross_entropy + column-sum partials of dlogits (n_partials rows of part_stride floats) + loss_out = loss_scale * sum(rows)
+    in one launch (V <= 128).  loss_scratch: fp32 [n_partials + 1], its LAST word the arrival counter (zero before the first
+    launch; the kernel leaves it at zero).  Returns the per-row losses."""
+    _chk(logits, "logits", torch.float32, contiguous=False)
+    _chk(targets, "targets", torch.int64)
+    _chk(dlogits, "dlogits", contiguous=False)
+    M = logits.shape[0]
+    if loss_rows is None:
+        loss_rows = torch.empty((M,), dtype=torch.float32, device=logits.device)
+    if colsum_part is not None:
+        _chk(colsum_part, "colsum_part", torch.float32, contiguous=False)
+    cnt = None
+    if loss_out is not None:
+        _chk(loss_out, "loss_out", torch.float32)
+        _chk(loss_scratch, "loss_scratch", torch.float32)
+        if loss_scratch.numel() < n_partials + 1:
+            raise ValueError("cross_entropy_fused: loss_scratch needs n_partials + 1 words")
+        cnt = loss_scratch.data_ptr() + 4 * n_partials
+    check(lib.dg_cross_entropy_fused(_p(logits), _ld(logits), _p(targets), _p(loss_rows), _p(dlogits), _ld(dlogits), dt_code(dlogits.dtype),
+                                     float(grad_scale), M, V, _p(colsum_part), part_stride, n_partials,
+                                     _p(loss_scratch) if loss_out is not None else None, cnt, _p(loss_out), float(loss_scale), _stream()),
+          "dg_cross_entropy_fused")
+    return loss_rows
+
+
 def reduce_sum(x: Tensor, scale: float, out: Optional[Tensor] = None) -> Tensor:
     _chk(x, "x", torch.float32)
     if out is None:
@@ -519,9 +551,10 @@ def softmax_rows(logits: Tensor) -> Tensor:
 
 
 def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor, rng_state: Tensor, grad_scale: float = 1.0,
-               shadow_bf16: Optional[Tensor] = None, n: Optional[int] = None) -> None:
+               shadow_bf16: Optional[Tensor] = None, n: Optional[int] = None, advance: bool = False) -> None:
+    """advance: the launch also moves the step word of rng_state on (what state_advance does, without its launch)"""
     for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (hyper, "hyper")):
         _chk(t, nm, torch.float32)
     n = p.numel() if n is None else n
-    check(lib.dg_adamw_step(_p(p), _p(g), _p(m), _p(v), n, _p(hyper), _p(rng_state), float(grad_scale), _p(shadow_bf16), _stream()),
-          "dg_adamw_step")
+    check(lib.dg_adamw_step(_p(p), _p(g), _p(m), _p(v), n, _p(hyper), _p(rng_state), float(grad_scale), _p(shadow_bf16), int(advance),
+                            _stream()), "dg_adamw_step")

@@ -5,7 +5,7 @@
 
 MI355X-first: on the first step the parameters that have a gradient are moved into ONE flat fp32 buffer (their
 ``.data`` become views of it, so ``state_dict()`` keeps working), with flat ``m`` / ``v`` / gradient buffers beside it:
-a step is one fused copy of the gradients, one ``dg_adamw_step`` launch and one step-counter launch instead of two
+a step is one fused copy of the gradients, one ``dg_adamw_step`` launch (which also moves the step counter on) instead of two
 launches per parameter tensor (168 for the tiny TransformerLM).  With a process group the flat gradient is
 all-reduced (SUM) first and the kernel applies 1 / world: data-parallel training for all six models."""
 from __future__ import annotations
@@ -91,6 +91,5 @@ class AdamW(torch.optim.Optimizer):
                 import torch.distributed as dist
                 dist.all_reduce(fl.g, op=dist.ReduceOp.SUM, group=self.process_group)
                 scale = 1.0 / self.world_size
-            ops.adamw_step(fl.flat, fl.g, fl.m, fl.v, fl.hyper, fl.t, grad_scale=scale)
-            ops.state_advance(fl.t)
+            ops.adamw_step(fl.flat, fl.g, fl.m, fl.v, fl.hyper, fl.t, grad_scale=scale, advance=True)
         return loss

@@ -22,9 +22,9 @@
  *
  * Dropout stream: a keep decision is a stateless hash of (seed, step, site, element index)
  * (csrc/common.h: dg_keep): elements 2i and 2i + 1 read the low / high 16 bits of one 32-bit
- * word hash(key, i) and are kept iff that field >= floor(p * 65536).  `rng_state` points at 4 device uint32: {seed_lo, seed_hi, step, 0};
- * the step word is advanced on the device (dg_state_advance) so a captured graph replays with
- * fresh masks.  A NULL rng_state or p == 0 disables dropout (eval mode).
+ * word hash(key, i) and are kept iff that field >= floor(p * 65536).
+ * `rng_state` points at 4 device uint32: {seed_lo, seed_hi, step, 0 (scratch of dg_adamw_step's advance)}; the step word is
+ * advanced on the device (dg_state_advance, or inside dg_adamw_step) so a captured graph replays with fresh masks.  A NULL rng_state or p == 0 disables dropout (eval mode).
  */
 #ifndef DRAKEGPT_HIP_H
 #define DRAKEGPT_HIP_H
@@ -295,6 +295,14 @@ int dg_cross_entropy(const void* logits, int logits_dtype, int64_t ldl, const in
                      void* dlogits, int64_t ldd, int dtype, float grad_scale,
                      const float* grad_scale_dev /* nullable: multiplies grad_scale */,
                      int M, int V, void* stream);
+/* The loss head of a captured step at a small vocabulary (ldd <= 128, fp32 logits): dg_cross_entropy + the column sums of
+ * the gradient (lm_head bias gradient: partial row b of colsum_part = rows [b * ceil(M / n_partials), ...), fp32, nullable) +
+ * the scalar loss (loss_out[0] = loss_scale * sum of loss_rows, added in a fixed order by the workgroup that finishes last;
+ * loss_part: n_partials floats of scratch, loss_counter: one device word, zero before the first launch and again after
+ * every launch; all three nullable together) in ONE launch of n_partials (<= 2048) workgroups. */
+int dg_cross_entropy_fused(const float* logits, int64_t ldl, const int64_t* targets, float* loss_rows, void* dlogits, int64_t ldd,
+                           int dtype, float grad_scale, int M, int V, float* colsum_part, int64_t part_stride, int n_partials,
+                           float* loss_part, uint32_t* loss_counter, float* loss_out, float loss_scale, void* stream);
 /* out[0] = scale * sum_i x[i] (single workgroup, fixed order). */
 int dg_reduce_sum(const float* x, int64_t n, float scale, float* out, void* stream);
 
@@ -308,9 +316,11 @@ int dg_softmax_rows(const float* logits, int64_t ldl, float* probs, int64_t ldp,
  *   p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
  *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),   t = rng_state.step + 1
  * hyper (device): {lr, beta1, beta2, eps, weight_decay}.  grad_scale multiplies g first
- * (1/world_size after a sum all-reduce).  Optionally refreshes a bf16 shadow copy of p. */
+ * (1/world_size after a sum all-reduce).  Optionally refreshes a bf16 shadow copy of p.
+ * advance_step != 0: the launch also does dg_state_advance -- the workgroup that finishes last writes step + 1 (word 3 of
+ * rng_state is its arrival counter: zero before and after every launch). */
 int dg_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
-                  const uint32_t* rng_state, float grad_scale, void* shadow_bf16, void* stream);
+                  uint32_t* rng_state, float grad_scale, void* shadow_bf16, int advance_step, void* stream);
 
 #ifdef __cplusplus
 }

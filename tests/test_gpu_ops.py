@@ -521,6 +521,44 @@ def test_cross_entropy_and_reduce(dev):
                 assert torch.all(dl[:, V:] == 0)
 
 
+@pytest.mark.parametrize("M,V,ldl,ldd,n", [(16384, 80, 128, 128, 256), (1000, 80, 80, 88, 7), (48, 7, 7, 8, 3), (256, 128, 128, 128, 2048)])
+def test_cross_entropy_fused_loss_head(dev, M, V, ldl, ldd, n):
+    """the one-launch loss head of the captured step (ref: F.cross_entropy at src/model.py:604-607 + the lm_head bias gradient):
+    per-row losses, gradient rows, column-sum partials and the mean loss against fp64; the arrival counter is back at zero, so a
+    second launch (new data) gives the new loss; launch after launch the loss is bit-identical"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + V)
+    for dt in (torch.bfloat16, torch.float32):
+        scratch = torch.zeros(n + 1, device=dev)
+        for trial in range(2):
+            buf = torch.full((M, ldl), 99.0)
+            buf[:, :V] = torch.randn(M, V, generator=g) * 3
+            tgt = torch.randint(0, V, (M,), generator=g)
+            x = buf[:, :V].double()
+            ref_rows = torch.logsumexp(x, 1) - x[torch.arange(M), tgt]
+            ref_grad = (torch.softmax(x, 1) - torch.nn.functional.one_hot(tgt, V)) / M
+            dl = torch.full((M, ldd), float("nan"), dtype=dt, device=dev)
+            part = torch.full((n, 200), float("nan"), device=dev)
+            loss = torch.full((), float("nan"), device=dev)
+            logits = buf.to(dev)[:, :V]
+            assert ops.cross_entropy_fused_supported(logits, dl, n)
+            rows = ops.cross_entropy_fused(logits, tgt.to(dev), V, dl, 1.0 / M, part[:, 3:], 200, n, scratch, loss, 1.0 / M)
+            torch.cuda.synchronize()
+            assert rel(rows, ref_rows) < 1e-6
+            assert abs(loss.item() - ref_rows.mean().item()) < 1e-5 * max(1.0, ref_rows.mean().item())
+            assert rel(dl[:, :V], ref_grad) < (1e-6 if dt == torch.float32 else 5e-3) and torch.all(dl[:, V:] == 0)
+            assert rel(part[:, 3:3 + V].double().sum(0), ref_grad.sum(0)) < 1e-4 or ref_grad.sum(0).abs().max() < 1e-6
+            assert torch.isnan(part[:, :3]).all() and torch.isnan(part[:, 3 + V:]).all()
+            assert scratch[n].view(torch.int32).item() == 0
+            loss2 = torch.zeros((), device=dev)
+            ops.cross_entropy_fused(logits, tgt.to(dev), V, dl, 1.0 / M, None, 0, n, scratch, loss2, 1.0 / M)
+            assert loss2.item() == loss.item()
+    big = torch.zeros((8, 136), dtype=torch.bfloat16, device=dev)
+    assert not ops.cross_entropy_fused_supported(torch.zeros((8, 130), device=dev), big, 4)
+    with pytest.raises(RuntimeError):
+        ops.cross_entropy_fused(torch.zeros((8, 130), device=dev), torch.zeros(8, dtype=torch.long, device=dev), 130, big, 1.0, None, 0, 4, None, None, 1.0)
+
+
 def test_cross_entropy_bf16_logits_in_place(dev):
     """large-vocabulary form: bf16 logits [M, ld] overwritten in place by their bf16 gradient (the engine at V = 50257); loss
     and gradient against fp64 on the same bf16 logits, padding columns zeroed, fp32 logits still refuse to alias"""
@@ -615,10 +653,11 @@ def test_colsum_bf16(dev, M, N, G, ld):
     assert rel(cs, A[:, :N].double().sum(0)) < 1e-5
 
 
-def test_adamw_matches_oracle(dev):
+@pytest.mark.parametrize("n,advance", [(10007, False), (10007, True), (3_000_001, True)])
+def test_adamw_matches_oracle(dev, n, advance):
+    """advance: the step word moves on inside the AdamW launch (last workgroup to arrive), as dg_state_advance does"""
     from oracle import drake_ref as R
     ops = _ops()
-    n = 10007
     g = torch.Generator().manual_seed(9)
     p0 = torch.randn(n, generator=g)
     params = {"w": p0.clone()}
@@ -633,8 +672,10 @@ def test_adamw_matches_oracle(dev):
     for it in range(4):
         gr = torch.randn(n, generator=g)
         opt.step(params, {"w": gr})
-        ops.adamw_step(pd, gr.to(dev), m, v, hyper, st, shadow_bf16=shadow)
-        ops.state_advance(st)
+        ops.adamw_step(pd, gr.to(dev), m, v, hyper, st, shadow_bf16=shadow, advance=advance)
+        if not advance:
+            ops.state_advance(st)
+        assert st.tolist()[2:] == [it + 1, 0]
     assert maxabs(pd, params["w"]) < 2e-6
     assert torch.equal(shadow.cpu(), pd.cpu().bfloat16())
 
