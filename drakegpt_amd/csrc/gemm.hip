@@ -291,6 +291,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
                (!a->residual || ((a->ldr % 4 == 0) && dg_aligned16(a->residual)));
     p.mask_vec_ok = a->relu_mask && (a->ldmask % 4 == 0) && ((((uintptr_t)a->relu_mask) % (4 * esz)) == 0);
     { static const int dbg = [] { const char* e = getenv("DG_GEMM_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
+    { static const int rpf = [] { const char* e = getenv("DG_NT_RESPF"); return e ? atoi(e) : 0; }(); p.res_prefetch = rpf; }
     p.stamps = g_stamp_buffer;
     const int tiles_m = (a->M + BM - 1) / BM;
     p.tiles_n = (a->N + BN - 1) / BN;

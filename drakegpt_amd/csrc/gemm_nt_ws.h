@@ -57,6 +57,7 @@ struct NtParams {
     unsigned long long* stamps;   // diagnostic build aid: per-workgroup s_memtime stamps (NULL in production)
     int dbg;      // ablation only (DG_GEMM_DBG): 1 = no operand loads after the first stage, 2 = no LDS reads / MFMA, 3 = no stores, 4 = 1 + 3
     const float* scale_a; const float* scale_b;   // fp8 operands: per-tensor dequantisation factors (device scalars), acc *= sa * sb
+    int res_prefetch;             // EPI 3 / 7: loader waves touch the residual tile ahead of the epilogue (DG_NT_RESPF, default 0: measured slower)
 };
 
 template <int CTRL>
@@ -121,9 +122,37 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     const int lw = wave - 8;
     const char* srcA[PPA];
     const char* srcB[PPB];
+    // Residual prefetch (EPI 3 / 7): the epilogue of these GEMMs reads a 128 x BNW fp32 tile of the residual stream, from HBM,
+    // with the matrix cores idle.  The loader waves touch one dword of each of its 128-byte lines RES_LEAD K steps before the
+    // tile's last stage is issued, so that the lines are on their way into L2 while the K loop still runs.  The touches are
+    // issued in FRONT of that stage's LDS-DMA pieces: every counted vmcnt wait below stays correct (loads return in order).
+    // MEASURED (round 2, same box, DG_NT_RESPF=1 vs 0): proj 18.0 vs 16.7 us, second FFN Linear 30.0 vs 27.5 us, step 2.540 vs
+    // 2.507 ms -- SLOWER.  The epilogue's residual reads are not exposed latency; the touches are 768 more requests per tile on a
+    // memory path that is the bound already.  Kept as an A/B switch, default off.
+    constexpr bool RESPF = (EPI == 3 || EPI == 7) && (BNW % 32 == 0);
+    constexpr int RES_LEAD = 3;
+    constexpr int RES_LINES = 32 * (BNW / 32);                 // lines of one loader wave's 32 rows
+    constexpr int RES_NT = (RES_LINES + 63) / 64;
+    int cur_m0 = 0, cur_n0 = 0;
+    float res_touch[RESPF ? RES_NT : 1];
+    auto touch_residual = [&]() {
+        if constexpr (RESPF) {
+            if (!(p.vec_ok && p.residual && cur_m0 + BM <= p.M && cur_n0 + BNW <= p.N)) return;
+#pragma unroll
+            for (int j = 0; j < RES_NT; ++j) {
+                const int idx = j * 64 + lane;
+                if (idx < RES_LINES) {
+                    const int row = idx / (BNW / 32), line = idx % (BNW / 32);
+                    const float* a = p.residual + (int64_t)(cur_m0 + 32 * lw + row) * p.ldr + cur_n0 + 32 * line;
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(res_touch[j]) : "v"(a) : "memory");
+                }
+            }
+        }
+    };
     auto set_src = [&](int ti) {
         const int tile = dg_xcd_remap((int)blockIdx.x + ti * G, p.n_tiles);
         const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BNW;
+        cur_m0 = m0; cur_n0 = n0;
 #pragma unroll
         for (int i = 0; i < PPA; ++i) {
             int gm = m0 + (PPA * lw + i) * 8 + prow; if (gm > p.M - 1) gm = p.M - 1;
@@ -139,6 +168,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     auto issue = [&](int g) {
         char* base = lds + (g & (GL_NST - 1)) * STAGE;
         const int64_t koff = (int64_t)iss_kt * 128;
+        if (RESPF && p.res_prefetch && iss_kt == (nk > RES_LEAD ? nk - RES_LEAD : 0)) touch_residual();
         if (!((e_dbg == 1 || e_dbg == 4) && g > 0)) {           // ablation: no operand traffic after the first stage
 #pragma unroll
             for (int i = 0; i < PPA; ++i)
@@ -164,6 +194,12 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                          // publishes stage g+1; stage g-1's buffer is free
             if (g + GL_NST - 1 < total) issue(g + GL_NST - 1);
+        }
+        if constexpr (RESPF) {
+            // the touch registers stay reserved until every touch has returned (the compiler knows nothing of the loads in flight)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < RES_NT; ++j) asm volatile("" :: "v"(res_touch[j]));
         }
         return;
     }
