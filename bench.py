@@ -305,7 +305,7 @@ def kernel_roofline(eng, offsets, peak_tflops):
     hbm = []              # (symbol, bytes, closure)
     esz = lambda t: t.element_size()
     hbm_names = ("layernorm_fwd", "layernorm_bwd_fused", "layernorm_bwd", "cross_entropy", "adamw_step", "embed_fwd", "embed_bwd",
-                 "batch_gather", "batch_embed_fwd")
+                 "batch_gather", "batch_embed_fwd", "cross_entropy_fused")
     real_hbm = {n: getattr(ops, n) for n in hbm_names}
 
     def wrap(name, nbytes):
@@ -320,14 +320,16 @@ def kernel_roofline(eng, offsets, peak_tflops):
         # x fp32 in, y out (+ mean, rstd)
         "layernorm_fwd": wrap("layernorm_fwd", lambda r, x, g, b, od, *a, **k: x.numel() * (4 + esz(r[0])) + 8 * r[1].numel()),
         # dy, x, dresid in; dx (+ g) out
-        "layernorm_bwd_fused": wrap("layernorm_bwd_fused", lambda r, dy, x, *a, **k: x.numel() * (esz(dy) + 4 + (4 if a[3] is not None else 0) + 4 + esz(r[1]))),
+        "layernorm_bwd_fused": wrap("layernorm_bwd_fused", lambda r, dy, x, *a, **k: x.numel() * (esz(dy) + 4 + (esz(a[3]) if a[3] is not None else 0) + esz(r[0]) + esz(r[1]))),
         "layernorm_bwd": wrap("layernorm_bwd", lambda r, dy, x, g, mean, rstd, dresid, *a, **k: x.numel() * (esz(dy) + 4 + (4 if dresid is not None else 0) + 4)),
         # logits in, dlogits out
         "cross_entropy": wrap("cross_entropy", lambda r, logits, tg, V, dlogits=None, **k: logits.shape[0] * V * 4 + (dlogits.numel() * esz(dlogits) if dlogits is not None else 0)),
+        # the loss head in one launch: fp32 logits in, dlogits (padded width) out; partials and shares are noise
+        "cross_entropy_fused": wrap("cross_entropy_fused", lambda r, logits, tg, V, dlogits, *a, **k: logits.shape[0] * V * 4 + dlogits.numel() * esz(dlogits)),
         # p, g, m, v read; p, m, v (+ bf16 shadow) written
         "adamw_step": wrap("adamw_step", lambda r, p, g, m, v, hy, st, gs=1.0, shadow_bf16=None, n=None, advance=False: (n or p.numel()) * (28 + (2 if shadow_bf16 is not None else 0))),
         "embed_fwd": wrap("embed_fwd", lambda r, idx, tok, pos, out=None, onehot=None: r.numel() * 4 + idx.numel() * 8 + (onehot.numel() * 2 if onehot is not None else 0)),
-        "embed_bwd": wrap("embed_bwd", lambda r, idx, dx, dtok, dpos, V=None: dx.numel() * 4 + (dpos.numel() * 4 if dpos is not None else 0) + (dtok.numel() * 4 if dtok is not None else 0)),
+        "embed_bwd": wrap("embed_bwd", lambda r, idx, dx, dtok, dpos, V=None: dx.numel() * esz(dx) + (dpos.numel() * 4 if dpos is not None else 0) + (dtok.numel() * 4 if dtok is not None else 0)),
         "batch_gather": wrap("batch_gather", lambda r, corpus, offsets, T, x=None, y=None: offsets.numel() * T * 32),
         # ids gathered (x and x + 1 from the corpus), ids / targets and the fp32 stream written
         "batch_embed_fwd": wrap("batch_embed_fwd", lambda r, corpus, offs, st, ctl, x, y, tok, pos, onehot=None: r.numel() * 4 + x.numel() * 32 + (onehot.numel() * 2 if onehot is not None else 0)),
