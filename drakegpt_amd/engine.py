@@ -2,23 +2,25 @@
 
 One step = ref: src/train.py:143-151 (get_batch -> forward -> zero_grad -> backward -> AdamW.step)
 run as hand-sequenced HIP kernels with no autograd, captured once into a hipGraph and replayed:
-Python issues ~300 kernel launches at capture time and one graph launch per step afterwards.
+Python issues the step's 100 kernel launches (L = 6) once, at capture time, and one graph launch per step afterwards.
 
 MI355X-first layout (288 GB HBM: keep everything resident, nothing is re-packed per step):
   * ONE flat fp32 master buffer holds every parameter; the model's nn.Parameters (reference
     state_dict layout, per-head key/query/value) are re-pointed to be VIEWS into it, with each
     layer's heads laid out as one packed [3C, C] QKV operand.  Regions:
-        A  GEMM weights      (gradients arrive as S split-K slabs from the TN GEMMs)
+        A  GEMM weights      (gradients written by ONE grouped dW launch; fp32 mode: S split-K slabs from the TN GEMMs)
         B  biases, LayerNorm (gradients arrive as G row-chunk partials)
         E  embeddings        (gradients written directly)
         Z  ln_f              (exists for the checkpoint; no gradient, no optimizer update)
   * flat gradient / Adam m / Adam v buffers with the same layout; one fused AdamW launch, which
-    also refreshes the bf16 shadow copy of the weights; W^T shadows (dX operands) are refreshed by
-    one transpose launch per matrix;
-  * step counter, dropout seed and learning rate live in device memory so a replay sees fresh
-    dropout masks, the right bias correction and the scheduler's current lr;
+    also refreshes the bf16 shadow copy of the weights and moves the step counter on; the W^T shadows (dX
+    operands, one flat buffer) are refreshed by one batched transpose launch;
+  * step counter, dropout seed, learning rate and the staged block of window offsets live in device
+    memory, so a replay sees fresh dropout masks, the right bias correction, the scheduler's current lr
+    and its own row of offsets (get_batch runs inside the embedding launch);
   * data parallel: the flat gradient is all-reduced (RCCL via torch.distributed) between the
-    backward graph and the optimizer graph; ln_f is outside the reduced range on every rank.
+    backward graph and the optimizer graph -- or, bucketed, range by range while the next layer group's
+    backward graph runs (_dp_plan); ln_f is outside the reduced range on every rank.
 """
 from __future__ import annotations
 
