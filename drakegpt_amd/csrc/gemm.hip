@@ -775,6 +775,11 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped_kernel(TnGroup gp) {
 // 16-byte values from scratch per K half, each a memory round trip in front of an MFMA that a single wave per SIMD cannot
 // hide.  Kept as an A/B variant; the default stays WT 0.  (The default is also closer to its HBM bound than to its LDS bound:
 // 1.87 GB in 455 us = 4.1 TB/s of the ~5.2 TB/s the chip sustains.)
+// Also tried for WT 0 (round 2, same box, removed again): the NT kernel's barrier-in-the-middle loop -- second K half requested,
+// first half multiplied, barrier, next stage's first half requested, second half multiplied, with the factored fragment
+// addresses of the WT 1 branch so that the loop has no scratch traffic -- 466 us against 445 us with the reads and MFMAs held
+// in that order by sched_barriers, 594 us with the order left to the compiler.  The straight loop below already overlaps:
+// the two MFMA waves of a SIMD drift apart by themselves and one's reads run under the other's MFMAs.
 template <int WT>
 __global__ __launch_bounds__(WT ? 512 : 768) void gemm_tn_grouped256_kernel(TnGroup gp) {
     constexpr int NMW = WT ? 4 : 8;                // MFMA waves
