@@ -18,7 +18,7 @@ DG_F32 = 0
 DG_BF16 = 1
 DG_FP8_E4M3 = 2
 DG_FP8_E5M2 = 3
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class GemmNtArgs(C.Structure):
@@ -45,6 +45,10 @@ class GemmNtArgs(C.Structure):
         ("b_dtype", C.c_int32),
         ("scale_a", C.c_void_p),
         ("scale_b", C.c_void_p),
+        ("fp8_out", C.c_void_p), ("ld_fp8_out", C.c_int64),
+        ("fp8_out_parts2", C.c_void_p),
+        ("fp8_out_step", C.c_void_p),
+        ("fp8_out_scale_inv", C.c_void_p),
     ]
 
 
@@ -73,6 +77,7 @@ SIGNATURES = {
     "dg_layernorm_bwd_fused": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _vp, _u32, _vp, _vp],
     "dg_gemm_nt": [C.POINTER(GemmNtArgs), _vp],
     "dg_gemm_nt_sign_bits_supported": [C.POINTER(GemmNtArgs)],
+    "dg_gemm_nt_fp8_out_supported": [C.POINTER(GemmNtArgs)],
     "dg_gemm_nt_colsum_supported": [C.POINTER(GemmNtArgs)],
     "dg_gemm_nt_colsum_rows": [C.POINTER(GemmNtArgs)],
     "dg_gemm_nt_sign_bits_bytes": [_i, _i],

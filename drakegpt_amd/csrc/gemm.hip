@@ -212,6 +212,21 @@ static bool dg_nt_wide(int N) {
     static const int wide_mode = [] { const char* e = getenv("DG_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // 0 = square tiles only (A/B runs)
     return wide_mode && N % 192 == 0;
 }
+// fp8 copy of the output from the epilogue (EPI 8): the bias + ReLU + sign-bit form with e4m3 operands and a bf16 output,
+// every tile whole and on the vector path, and exactly DG_FP8_AMAX_PARTS persistent workgroups (one partial maximum each).
+extern "C" int dg_gemm_nt_fp8_out_supported(const dg_gemm_nt_args* a) {
+    if (!a || !dg_gemm_nt_sign_bits_supported(a) || a->in_dtype != DG_FP8_E4M3 || a->out_dtype != DG_BF16) return 0;
+    if (!a->bias || !a->relu || !a->sign_bits_out || a->relu_mask || a->residual || a->sign_bits || a->colsum_part ||
+        (a->dropout_p > 0.f && a->rng_state)) return 0;
+    static const int dbg = [] { const char* e = getenv("DG_GEMM_DBG"); return e ? atoi(e) : 0; }();
+    static const int off = [] { const char* e = getenv("DG_FP8_FUSED_OUT"); return e ? atoi(e) == 0 : 0; }();   // 0 = never (A/B runs)
+    if (dbg || g_stamp_buffer || off) return 0;
+    const int bn = dg_nt_wide(a->N) ? 192 : 128;
+    if (a->M % BM || a->N % bn || a->ldc % 8 || !dg_aligned16(a->C) || !dg_aligned16(a->bias)) return 0;
+    const int64_t n_tiles = (int64_t)(a->M / BM) * (a->N / bn);
+    return dg_num_cus() == DG_FP8_AMAX_PARTS && n_tiles >= DG_FP8_AMAX_PARTS;
+}
+
 extern "C" int64_t dg_gemm_nt_sign_bits_bytes(int M, int N) {
     if (M <= 0 || N <= 0) return 0;
     const int bn = dg_nt_wide(N) ? 192 : 128;
@@ -271,7 +286,12 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
     if (a->colsum_part && (!dg_gemm_nt_colsum_supported(a) || a->colsum_rows < dg_gemm_nt_colsum_rows(a) || a->colsum_ld < a->N ||
                            a->colsum_ld % 4 || !dg_aligned16(a->colsum_part)))
         return DG_ERR_ARG;
+    if (a->fp8_out && (!dg_gemm_nt_fp8_out_supported(a) || !a->fp8_out_parts2 || !a->fp8_out_step || !a->fp8_out_scale_inv ||
+                       a->ld_fp8_out < a->N || a->ld_fp8_out % 8 || (((uintptr_t)a->fp8_out) & 7)))
+        return DG_ERR_ARG;
     NtParams p;
+    p.q8 = (unsigned char*)a->fp8_out; p.ldq8 = a->ld_fp8_out; p.q_parts2 = a->fp8_out_parts2; p.q_step = a->fp8_out_step;
+    p.q_scale_inv = a->fp8_out_scale_inv;
     p.A = (const char*)a->A; p.lda_b = a->lda * esz;
     p.B = (const char*)a->B; p.ldb_b = a->ldb * esz;
     p.C = a->C; p.ldc = a->ldc;
@@ -317,7 +337,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
             const bool plain = !a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits && !a->sign_bits_out;
             if (p.dbg == 0 && !p.stamps) {
                 if (plain) epi = 1;
-                else if (a->out_dtype == DG_BF16 && a->bias && a->relu && a->sign_bits_out && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits) epi = 2;
+                else if (a->out_dtype == DG_BF16 && a->bias && a->relu && a->sign_bits_out && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits) epi = a->fp8_out ? 8 : 2;
                 else if (a->bias && p.drop && a->residual && !a->relu && !a->relu_mask && !a->sign_bits && !a->sign_bits_out) epi = 3;
                 else if (a->out_dtype == DG_BF16 && pf && !a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits_out) epi = a->colsum_part ? 6 : 4;
                 else if (a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits && !a->sign_bits_out) epi = 5;

@@ -13,6 +13,7 @@ int dg_gemm_nt_fp8_launch(const NtParams& p, int f8, int out_dtype, bool pf, boo
 #define FWD(NJ_) do { \
         if (epi == 1 && ob) L(bf16_t, false, NJ_, 1, 1); \
         else if (epi == 2) L(bf16_t, false, NJ_, 2, 1); \
+        else if (epi == 8) L(bf16_t, false, NJ_, 8, 1); \
         else if (epi == 3 && ob) L(bf16_t, false, NJ_, 3, 1); \
         else if (epi == 3) L(float, false, NJ_, 3, 1); \
         else if (epi == 7 && ob) L(bf16_t, false, NJ_, 7, 1); \

@@ -58,6 +58,11 @@ struct NtParams {
     int dbg;      // ablation only (DG_GEMM_DBG): 1 = no operand loads after the first stage, 2 = no LDS reads / MFMA, 3 = no stores, 4 = 1 + 3
     const float* scale_a; const float* scale_b;   // fp8 operands: per-tensor dequantisation factors (device scalars), acc *= sa * sb
     int res_prefetch;             // EPI 3 / 7: loader waves touch the residual tile ahead of the epilogue (DG_NT_RESPF, default 0: measured slower)
+    // EPI 8: the output is ALSO written as e4m3 (the next GEMM's fp8 operand) with delayed per-tensor scaling
+    unsigned char* q8; int64_t ldq8;          // [M][ldq8] bytes
+    float* q_parts2;                          // [2][256] partial maxima of the call site (dg_fp8_quantize_delayed's layout)
+    const uint32_t* q_step;                   // device step word: slot (step & 1) is written, the other one read
+    float* q_scale_inv;                       // [1]: dequantisation factor for the consumer
 };
 
 template <int CTRL>
@@ -84,7 +89,9 @@ __device__ __forceinline__ float dpp_f32(float x) {
 // DG_GEMM_DBG ablations and s_memtime stamps); 1 = plain store; 2 = bias + ReLU + sign-bit emission (Linear+ReLU of
 // FeedForward); 3 = bias + dropout + residual (proj / second FFN Linear); 4 = sign-bit mask (dX of the second FFN Linear);
 // 5 = bias only (lm_head: 1.65 GB of fp32 logits at the GPT-2 vocabulary); 6 = 4 + column sums; 7 = bias + residual (3 at dropout 0:
-// eval mode and p = 0 training ran the generic form, 2.64 instead of 2.54 ms per step).
+// eval mode and p = 0 training ran the generic form, 2.64 instead of 2.54 ms per step); 8 = 2 + an e4m3 copy of the output with
+// delayed per-tensor scaling (fp8 mode, first FFN Linear: the second one's operand needs no cast launch that re-reads the
+// 100 MB hidden activation; whole tiles only, exactly 256 workgroups -- one partial maximum per workgroup).
 // The specialised forms are straight-line code: no uniform branch per option and per K step, so the scheduler can overlap
 // the epilogue's loads, lane exchanges and stores.
 // F8: 0 = bf16 operands (two v_mfma_f32_16x16x32_bf16 per 128-byte K step and 16 x 16 block); 1 / 2 = OCP fp8 operands, ONE
@@ -95,14 +102,14 @@ __device__ __forceinline__ float dpp_f32(float x) {
 template <typename TO, bool PF, int NJ, int EPI, int F8 = 0>
 __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     constexpr bool GEN = EPI == 0;
-    const float* const e_bias = (GEN || EPI == 2 || EPI == 3 || EPI == 5 || EPI == 7) ? p.bias : nullptr;
-    const int e_relu = GEN ? p.relu : (EPI == 2 ? 1 : 0);
+    const float* const e_bias = (GEN || EPI == 2 || EPI == 3 || EPI == 5 || EPI == 7 || EPI == 8) ? p.bias : nullptr;
+    const int e_relu = GEN ? p.relu : ((EPI == 2 || EPI == 8) ? 1 : 0);
     const void* const e_mask = GEN ? p.relu_mask : nullptr;
     const int e_drop = (GEN || EPI == 3) ? p.drop : 0;
     const float* const e_res = (GEN || EPI == 3 || EPI == 7) ? p.residual : nullptr;
     const unsigned char* const e_bin = (GEN || EPI == 4 || EPI == 6) ? p.bits_in : nullptr;
     float* const e_cs = (EPI == 6) ? p.colsum_part : nullptr;    // interior tiles only: the host picks EPI 6 only when every tile is one
-    unsigned char* const e_bout = (GEN || EPI == 2) ? p.bits_out : nullptr;
+    unsigned char* const e_bout = (GEN || EPI == 2 || EPI == 8) ? p.bits_out : nullptr;
     const int e_dbg = GEN ? p.dbg : 0;
     unsigned long long* const e_stamps = GEN ? p.stamps : nullptr;
     constexpr int BNW = NJ * 32;                               // tile width
@@ -242,6 +249,22 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     };
     float e_sab = 1.f;
     if constexpr (F8 != 0) e_sab = p.scale_a[0] * p.scale_b[0];
+    // EPI 8: scale of the e4m3 copy from the maxima this call site recorded one step ago; this launch's maximum goes to the
+    // other slot, one entry per workgroup (zeroed here by its first wave, raised by all eight at the end of the launch)
+    float q_sc = 1.f, q_m = 0.f;
+    float* q_next = nullptr;
+    if constexpr (EPI == 8) {
+        const int parity = (int)(p.q_step[2] & 1u);
+        const float* prev = p.q_parts2 + (parity ^ 1) * 256;
+        q_next = p.q_parts2 + parity * 256;
+        float am = fmaxf(fmaxf(prev[lane], prev[64 + lane]), fmaxf(prev[128 + lane], prev[192 + lane]));
+        am = wave_max(am);
+        q_sc = am > 0.f ? 448.f / am : 1.f;                   // (fp8_scale_of, e4m3)
+        if (wave == 0 && lane == 0) {
+            q_next[blockIdx.x] = 0.f;
+            if (blockIdx.x == 0) p.q_scale_inv[0] = 1.f / q_sc;
+        }
+    }
     uint32_t key = 0;
     if (e_drop) key = dg_site_key_dev(p.rng_state, p.site);
     TO* Cp = (TO*)p.C;
@@ -505,6 +528,16 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                     for (int e = 0; e < 8; ++e) bm |= (v[e] > 0.f ? 1u : 0u) << e;
                     e_bout[((((int64_t)tile * 8 + wave) * (NJ / 2) + q) * 2 + i) * 64 + lane] = (unsigned char)bm;
                 }
+                if constexpr (EPI == 8) {                     // v >= 0 behind the ReLU: |v| = v, only the upper clamp matters
+                    float w8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { q_m = fmaxf(q_m, v[e]); w8[e] = fminf(v[e] * q_sc, 448.f); }
+                    int lo = 0, hi = 0;
+                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(w8[0], w8[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(w8[2], w8[3], lo, true);
+                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(w8[4], w8[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(w8[6], w8[7], hi, true);
+                    typedef int i32x2 __attribute__((ext_vector_type(2)));
+                    *(i32x2*)(p.q8 + (int64_t)row * p.ldq8 + col) = (i32x2){lo, hi};
+                }
                 TO* cp = Cp + (int64_t)row * p.ldc + col;
                 if constexpr (sizeof(TO) == 4) {
                     *(f32x4*)cp = (f32x4){v[0], v[1], v[2], v[3]};
@@ -570,6 +603,11 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
         }
         stamp();
         if (++kt == nk) { finish_tile(tile_i); kt = 0; ++tile_i; stamp(); }
+    }
+    if constexpr (EPI == 8) {
+        q_m = wave_max(q_m);
+        // non-negative floats order like their bit patterns
+        if (lane == 0) __hip_atomic_fetch_max((unsigned*)(q_next + blockIdx.x), __builtin_bit_cast(unsigned, q_m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (EPI == 6) {
         if (p.cs_accum && total > 0) {

@@ -214,8 +214,11 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
             residual: Optional[Tensor] = None, dropout_p: float = 0.0, rng_state: Optional[Tensor] = None,
             site: int = 0, out: Optional[Tensor] = None, sign_bits_out: Optional[Tensor] = None,
             sign_bits: Optional[Tensor] = None, colsum_part: Optional[Tensor] = None,
-            scale_a: Optional[Tensor] = None, scale_b: Optional[Tensor] = None) -> Tensor:
+            scale_a: Optional[Tensor] = None, scale_b: Optional[Tensor] = None, fp8_out=None) -> Tensor:
     """out[M,N] = epilogue(A[M,K] @ Bm[N,K]^T).  A/Bm may carry padding columns beyond K (ld > K).
+    fp8_out: (q8 [M, N] float8_e4m3fn, parts2 fp32 [2 * FP8_AMAX_PARTS], step_state, scale_inv fp32 [1]) -- the epilogue also
+    writes the output as e4m3 with delayed scaling (what fp8_quantize_delayed would make of it); only where
+    gemm_nt_fp8_out_supported(M, N, K).
     fp8: A float8_e4m3fn (activations) or float8_e5m2 (gradients), Bm float8_e4m3fn, scale_a / scale_b the device scalars
     fp8_quantize returned (out = epilogue(scale_a * scale_b * A @ Bm^T)); K % 128 == 0.
     sign_bits_out / sign_bits: opaque uint8 buffer (new_sign_bits) holding one bit per element, out > 0.
@@ -270,8 +273,28 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
         if colsum_part.shape[1] < N:
             raise RuntimeError("gemm_nt: colsum_part must have N columns")
         a.colsum_part, a.colsum_ld, a.colsum_rows = _p(colsum_part), _ld(colsum_part), colsum_part.shape[0]
+    if fp8_out is not None:
+        q8, parts2, step_state, q_scale_inv = fp8_out
+        _chk(q8, "fp8_out", torch.float8_e4m3fn, contiguous=False)
+        _chk(parts2, "fp8_out parts2", torch.float32)
+        _chk(q_scale_inv, "fp8_out scale_inv", torch.float32)
+        if q8.shape != (M, N) or parts2.numel() < 2 * FP8_AMAX_PARTS:
+            raise RuntimeError("gemm_nt: fp8_out must be [M, N] with a [2 * FP8_AMAX_PARTS] history")
+        a.fp8_out, a.ld_fp8_out = _p(q8), _ld(q8)
+        a.fp8_out_parts2, a.fp8_out_step, a.fp8_out_scale_inv = _p(parts2), _p(step_state), _p(q_scale_inv)
     check(lib.dg_gemm_nt(C.byref(a), _stream()), "dg_gemm_nt")
     return out
+
+
+def gemm_nt_fp8_out_supported(M: int, N: int, K: int) -> bool:
+    """can the bias + ReLU + sign-bit form of dg_gemm_nt on e4m3 operands also emit its output as e4m3 (fp8_out)?"""
+    a = GemmNtArgs()
+    a.M, a.N, a.K = M, N, K
+    a.in_dtype, a.out_dtype = dt_code(torch.float8_e4m3fn), dt_code(torch.bfloat16)
+    a.ldc = N
+    a.C = a.bias = a.sign_bits_out = 16        # any non-null, aligned pointer value: the query only looks at which operands are present
+    a.relu = 1
+    return bool(lib.dg_gemm_nt_fp8_out_supported(C.byref(a)))
 
 
 def gemm_nt_sign_bits_supported(dtype: torch.dtype, N: int, K: int, in_dtype: Optional[torch.dtype] = None) -> bool:

@@ -191,14 +191,26 @@ def _quantize_operand(run: Run, x: Tensor, fmt: torch.dtype, site: Optional[str]
     return ops.fp8_quantize_delayed(x, fmt, parts2, run.step_word)
 
 
-def linear_nt(run: Run, x: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: Optional[str] = None, **epi) -> Tensor:
+def linear_nt(run: Run, x: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: Optional[str] = None, x8=None, **epi) -> Tensor:
     """forward of a block Linear: epilogue(x W^T), x [M, in] in the activation dtype, W [out, in] the fp32 master.
-    fp8 mode: x is quantised to e4m3 (see _quantize_operand), W comes as its persistent e4m3 shadow."""
+    fp8 mode: x is quantised to e4m3 (see _quantize_operand) -- or arrives quantised already as x8 = (e4m3 copy, scale) from
+    the epilogue that produced it -- and W comes as its persistent e4m3 shadow."""
     if run.fp8 and fp8_k_ok(W.shape[1]) and x.is_contiguous() and x.dtype == torch.bfloat16:
         wq, ws = run.weights.fwd8(W)
-        xq, xs = _quantize_operand(run, x, E4M3, fp8_site)
+        xq, xs = x8 if x8 is not None else _quantize_operand(run, x, E4M3, fp8_site)
         return ops.gemm_nt(xq, wq, out_dtype, scale_a=xs, scale_b=ws, **epi)
     return ops.gemm_nt(x, run.weights.fwd(W), out_dtype, **epi)
+
+
+def _fused_fp8_out(run: Run, site: str, M: int, N: int, K: int, dev):
+    """fp8_out argument for the GEMM that PRODUCES the operand of call site `site` (training engine, history seeded): the e4m3
+    copy leaves that GEMM's epilogue and the site's cast launch -- which would re-read the whole tensor -- disappears"""
+    if not run.fp8 or run.fp8_sites is None or run.fp8_seed or site not in run.fp8_sites or run.step_word is None:
+        return None
+    if not (fp8_k_ok(K) and fp8_k_ok(N) and ops.gemm_nt_fp8_out_supported(M, N, K)):
+        return None
+    return (torch.empty((M, N), dtype=E4M3, device=dev), run.fp8_sites[site], run.step_word,
+            torch.empty((1,), dtype=torch.float32, device=dev))
 
 
 def linear_dx(run: Run, g: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: Optional[str] = None, **epi) -> Tensor:
@@ -318,9 +330,10 @@ def ffn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor
     if (ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w1.shape[1], in_dtype=_op_dtype(run, w1.shape[1]))
             and ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w2.shape[0], in_dtype=_op_dtype(run, w2.shape[0], grad=True))):
         bits = ops.new_sign_bits(h.shape[0], w1.shape[0], h.device)
-    f = linear_nt(run, h, w1, run.act, fp8_site=f"{layer}.h2", bias=b1, relu=True, sign_bits_out=bits)
-    y = linear_nt(run, f, w2, out_dtype, fp8_site=f"{layer}.f", bias=b2, dropout_p=run.p(p), rng_state=run.rng,
-                  site=site_ffn(layer), residual=x2d if residual else None)
+    f8 = _fused_fp8_out(run, f"{layer}.f", h.shape[0], w1.shape[0], w1.shape[1], h.device) if bits is not None else None
+    f = linear_nt(run, h, w1, run.act, fp8_site=f"{layer}.h2", bias=b1, relu=True, sign_bits_out=bits, fp8_out=f8)
+    y = linear_nt(run, f, w2, out_dtype, fp8_site=f"{layer}.f", x8=(f8[0], f8[3]) if f8 is not None else None, bias=b2,
+                  dropout_p=run.p(p), rng_state=run.rng, site=site_ffn(layer), residual=x2d if residual else None)
     return y, (x2d, h, mean, rstd, f, bits)
 
 

@@ -45,7 +45,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 10   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 11   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -155,9 +155,21 @@ typedef struct dg_gemm_nt_args {
     int32_t b_dtype;
     const float* scale_a;
     const float* scale_b;
+    /* fp8_out (nullable): the output is ALSO written as OCP e4m3, [M][ld_fp8_out] bytes -- the operand of the next fp8 GEMM,
+     * without a cast launch that re-reads C -- with delayed per-tensor scaling exactly as dg_fp8_quantize_delayed does it:
+     * fp8_out_parts2 = [2][DG_FP8_AMAX_PARTS] partial maxima of the call site (slot rng_state-style step & 1 written, the other
+     * read; fp8_out_step = the device step word array), *fp8_out_scale_inv = the factor the consumer multiplies back.  The cast
+     * sees the fp32 value (before the rounding to out_dtype).  Only where dg_gemm_nt_fp8_out_supported(args) is non-zero
+     * (fp8 e4m3 operands, bf16 out, bias + ReLU + sign_bits_out epilogue, whole tiles, exactly DG_FP8_AMAX_PARTS workgroups:
+     * the first FFN Linear of the engine's step); DG_ERR_ARG otherwise. */
+    void* fp8_out; int64_t ld_fp8_out;
+    float* fp8_out_parts2;
+    const uint32_t* fp8_out_step;
+    float* fp8_out_scale_inv;
 } dg_gemm_nt_args;
 int dg_gemm_nt(const dg_gemm_nt_args* args, void* stream);
 int dg_gemm_nt_sign_bits_supported(const dg_gemm_nt_args* args);
+int dg_gemm_nt_fp8_out_supported(const dg_gemm_nt_args* args);
 /* colsum_part: the epilogue also leaves the column sums of C (fp32, of the values before rounding to out_dtype) as
  * dg_gemm_nt_colsum_rows(args) partial rows: sum them with dg_reduce_partials.  Which rows of C a partial row covers is
  * the kernel's business (one per 32 rows of C, or one per workgroup and wave row when a workgroup's tiles share their

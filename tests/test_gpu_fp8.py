@@ -150,6 +150,60 @@ def test_gemm_nt_fp8_epilogues(dev, M, N, K):
     assert rel(dx, (G.double() @ Bt.double().T) * (0.01 * 0.02)) < 3e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 1536, 256), (8192, 1024, 384)])
+def test_gemm_nt_fp8_out_from_the_epilogue(dev, M, N, K):
+    """fp8_out: the bias + ReLU + sign-bit GEMM also leaves its output as e4m3 with delayed scaling (what a dg_fp8_quantize_delayed
+    launch on the output would produce, minus the launch and its re-read).  Against exact arithmetic: q8 = e4m3(out * 448 / amax_prev)
+    of the fp32 output; the slot of this step receives max(out); scale_inv = amax_prev / 448; the bf16 output and the sign bits
+    are those of the call without fp8_out, bit for bit; the next step (parity flipped) scales by the maximum just recorded."""
+    from drakegpt_amd import ops
+    g = torch.Generator().manual_seed(N + K)
+    A = _rand_fp8((M, K), E4, g, 2.0)
+    B = _rand_fp8((N, K), E4, g, 1.0)
+    bias = torch.randn(N, generator=g)
+    sa, sb = torch.tensor([0.013]), torch.tensor([0.021])
+    d = lambda t: t.to(dev)
+    assert ops.gemm_nt_fp8_out_supported(M, N, K) and not ops.gemm_nt_fp8_out_supported(M - 128, 128, K)
+    ref = torch.relu((A.double() @ B.double().T) * (0.013 * 0.021) + bias.double())
+    bits0 = ops.new_sign_bits(M, N, dev)
+    f0 = ops.gemm_nt(d(A), d(B), torch.bfloat16, bias=d(bias), relu=True, sign_bits_out=bits0, scale_a=d(sa), scale_b=d(sb))
+    P = ops.FP8_AMAX_PARTS
+    parts2 = torch.zeros(2 * P, device=dev)
+    amax_prev = 0.8 * ref.max().item()                        # last step's range was smaller: the top of this one clips
+    parts2[P:] = torch.rand(P, generator=g).to(dev) * 0.1
+    parts2[P + 17] = amax_prev                                # step 4 is even: slot 1 is read, slot 0 written
+    parts2[:P] = 123.0                                        # stale values in the slot to be written
+    st = ops.new_rng_state(1, dev, 4)
+    q8 = torch.zeros((M, N), dtype=E4, device=dev)
+    sinv = torch.zeros(1, device=dev)
+    bits = ops.new_sign_bits(M, N, dev)
+    f = ops.gemm_nt(d(A), d(B), torch.bfloat16, bias=d(bias), relu=True, sign_bits_out=bits, scale_a=d(sa), scale_b=d(sb),
+                    fp8_out=(q8, parts2, st, sinv))
+    torch.cuda.synchronize()
+    assert torch.equal(f, f0) and torch.equal(bits, bits0)
+    assert abs(sinv.item() - amax_prev / 448.0) < 1e-6 * amax_prev
+    got = q8.float().double().cpu() * sinv.item()
+    want = ref.clamp(max=amax_prev)
+    # e4m3: 3 mantissa bits -> half an ulp is 2^-4 relative; subnormals below 2^-6 of the scaled range are absolute
+    err = (got - want).abs()
+    tol = want.abs() * 2.0 ** -4 + amax_prev / 448.0 * 2.0 ** -10 + 1e-5 * amax_prev
+    assert (err <= tol).all(), (err - tol).max()
+    assert rel(got, want) < 0.04
+    rec = parts2[:P]
+    assert abs(rec.max().item() - ref.max().item()) < 1e-5 * ref.max().item() and rec.min().item() >= 0.0
+    assert torch.equal(parts2[P:].cpu()[17:18], torch.tensor([amax_prev], dtype=torch.float32))       # the read slot is untouched
+    # the cast launch on the bf16 output agrees up to the bf16 rounding of its input
+    q_ref, s_ref = ops.fp8_quantize_delayed(f0, E4, torch.cat([torch.zeros(P, device=dev), parts2[P:]]), st)
+    assert abs(s_ref.item() - sinv.item()) < 1e-7 and (q_ref.view(torch.uint8) != q8.view(torch.uint8)).float().mean().item() < 0.02
+    # next step: parity flips, the maximum recorded above is the scale
+    ops.state_advance(st)
+    ops.gemm_nt(d(A), d(B), torch.bfloat16, bias=d(bias), relu=True, sign_bits_out=bits, scale_a=d(sa), scale_b=d(sb), fp8_out=(q8, parts2, st, sinv))
+    assert abs(sinv.item() - ref.max().item() / 448.0) < 1e-5 * ref.max().item()
+    assert rel(q8.float().double().cpu() * sinv.item(), ref) < 0.04
+    with pytest.raises(RuntimeError):                        # not offered without the sign bits / for ragged shapes
+        ops.gemm_nt(d(A), d(B), torch.bfloat16, bias=d(bias), relu=True, scale_a=d(sa), scale_b=d(sb), fp8_out=(q8, parts2, st, sinv))
+
+
 def test_gemm_nt_fp8_argument_validation(dev):
     from drakegpt_amd import ops
     A = torch.zeros(128, 256, dtype=E4, device=dev)
