@@ -212,19 +212,25 @@ static bool dg_nt_wide(int N) {
     static const int wide_mode = [] { const char* e = getenv("DG_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // 0 = square tiles only (A/B runs)
     return wide_mode && N % 192 == 0;
 }
-// fp8 copy of the output from the epilogue (EPI 8): the bias + ReLU + sign-bit form with e4m3 operands and a bf16 output,
-// every tile whole and on the vector path, and exactly DG_FP8_AMAX_PARTS persistent workgroups (one partial maximum each).
+// fp8 copy of the output from the epilogue: (EPI 8) the bias + ReLU + sign-bit form with e4m3 operands -> e4m3 copy, or (EPI 9)
+// the sign-bit-masked dX form with column sums and e5m2 gradients -> e5m2 copy; bf16 output, every tile whole and on the
+// vector path, and exactly DG_FP8_AMAX_PARTS persistent workgroups (one partial maximum each).
+extern "C" int dg_gemm_nt_colsum_supported(const dg_gemm_nt_args* a);
 extern "C" int dg_gemm_nt_fp8_out_supported(const dg_gemm_nt_args* a) {
-    if (!a || !dg_gemm_nt_sign_bits_supported(a) || a->in_dtype != DG_FP8_E4M3 || a->out_dtype != DG_BF16) return 0;
-    if (!a->bias || !a->relu || !a->sign_bits_out || a->relu_mask || a->residual || a->sign_bits || a->colsum_part ||
-        (a->dropout_p > 0.f && a->rng_state)) return 0;
+    if (!a || !dg_gemm_nt_sign_bits_supported(a) || a->out_dtype != DG_BF16) return 0;
     static const int dbg = [] { const char* e = getenv("DG_GEMM_DBG"); return e ? atoi(e) : 0; }();
-    static const int off = [] { const char* e = getenv("DG_FP8_FUSED_OUT"); return e ? atoi(e) == 0 : 0; }();   // 0 = never (A/B runs)
-    if (dbg || g_stamp_buffer || off) return 0;
+    static const int mode = [] { const char* e = getenv("DG_FP8_FUSED_OUT"); return e ? atoi(e) : 3; }();   // bit 0: forward form, bit 1: dX form (A/B runs)
+    if (dbg || g_stamp_buffer) return 0;
     const int bn = dg_nt_wide(a->N) ? 192 : 128;
-    if (a->M % BM || a->N % bn || a->ldc % 8 || !dg_aligned16(a->C) || !dg_aligned16(a->bias)) return 0;
+    if (a->M % BM || a->N % bn || a->ldc % 8 || !dg_aligned16(a->C)) return 0;
     const int64_t n_tiles = (int64_t)(a->M / BM) * (a->N / bn);
-    return dg_num_cus() == DG_FP8_AMAX_PARTS && n_tiles >= DG_FP8_AMAX_PARTS;
+    if (dg_num_cus() != DG_FP8_AMAX_PARTS || n_tiles < DG_FP8_AMAX_PARTS) return 0;
+    if (a->in_dtype == DG_FP8_E4M3)
+        return (mode & 1) && a->bias && dg_aligned16(a->bias) && a->relu && a->sign_bits_out && !a->relu_mask && !a->residual && !a->sign_bits &&
+               !a->colsum_part && !(a->dropout_p > 0.f && a->rng_state);
+    if (a->in_dtype == DG_FP8_E5M2)
+        return (mode & 2) && a->colsum_part && dg_gemm_nt_colsum_supported(a);
+    return 0;
 }
 
 extern "C" int64_t dg_gemm_nt_sign_bits_bytes(int M, int N) {
@@ -339,7 +345,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
                 if (plain) epi = 1;
                 else if (a->out_dtype == DG_BF16 && a->bias && a->relu && a->sign_bits_out && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits) epi = a->fp8_out ? 8 : 2;
                 else if (a->bias && p.drop && a->residual && !a->relu && !a->relu_mask && !a->sign_bits && !a->sign_bits_out) epi = 3;
-                else if (a->out_dtype == DG_BF16 && pf && !a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits_out) epi = a->colsum_part ? 6 : 4;
+                else if (a->out_dtype == DG_BF16 && pf && !a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits_out) epi = a->colsum_part ? (a->fp8_out ? 9 : 6) : 4;
                 else if (a->bias && !a->relu && !a->relu_mask && !p.drop && !a->residual && !a->sign_bits && !a->sign_bits_out) epi = 5;
                 else if (a->bias && !p.drop && a->residual && !a->relu && !a->relu_mask && !a->sign_bits && !a->sign_bits_out) epi = 7;
             }

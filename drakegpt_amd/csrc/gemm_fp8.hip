@@ -24,6 +24,7 @@ int dg_gemm_nt_fp8_launch(const NtParams& p, int f8, int out_dtype, bool pf, boo
         if (epi == 1 && ob) L(bf16_t, false, NJ_, 1, 2); \
         else if (epi == 4) L(bf16_t, true, NJ_, 4, 2); \
         else if (epi == 6) L(bf16_t, true, NJ_, 6, 2); \
+        else if (epi == 9) L(bf16_t, true, NJ_, 9, 2); \
         else if (pf && ob) L(bf16_t, true, NJ_, 0, 2); \
         else if (ob) L(bf16_t, false, NJ_, 0, 2); \
         else L(float, false, NJ_, 0, 2); } while (0)

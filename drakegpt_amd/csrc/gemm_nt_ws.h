@@ -91,7 +91,8 @@ __device__ __forceinline__ float dpp_f32(float x) {
 // 5 = bias only (lm_head: 1.65 GB of fp32 logits at the GPT-2 vocabulary); 6 = 4 + column sums; 7 = bias + residual (3 at dropout 0:
 // eval mode and p = 0 training ran the generic form, 2.64 instead of 2.54 ms per step); 8 = 2 + an e4m3 copy of the output with
 // delayed per-tensor scaling (fp8 mode, first FFN Linear: the second one's operand needs no cast launch that re-reads the
-// 100 MB hidden activation; whole tiles only, exactly 256 workgroups -- one partial maximum per workgroup).
+// 100 MB hidden activation; whole tiles only, exactly 256 workgroups -- one partial maximum per workgroup); 9 = 6 + an e5m2 copy,
+// the same way (the hidden layer's pre-activation gradient, operand of the first FFN Linear's dX GEMM).
 // The specialised forms are straight-line code: no uniform branch per option and per K step, so the scheduler can overlap
 // the epilogue's loads, lane exchanges and stores.
 // F8: 0 = bf16 operands (two v_mfma_f32_16x16x32_bf16 per 128-byte K step and 16 x 16 block); 1 / 2 = OCP fp8 operands, ONE
@@ -107,8 +108,11 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     const void* const e_mask = GEN ? p.relu_mask : nullptr;
     const int e_drop = (GEN || EPI == 3) ? p.drop : 0;
     const float* const e_res = (GEN || EPI == 3 || EPI == 7) ? p.residual : nullptr;
-    const unsigned char* const e_bin = (GEN || EPI == 4 || EPI == 6) ? p.bits_in : nullptr;
-    float* const e_cs = (EPI == 6) ? p.colsum_part : nullptr;    // interior tiles only: the host picks EPI 6 only when every tile is one
+    const unsigned char* const e_bin = (GEN || EPI == 4 || EPI == 6 || EPI == 9) ? p.bits_in : nullptr;
+    float* const e_cs = (EPI == 6 || EPI == 9) ? p.colsum_part : nullptr;
+    constexpr bool CS = EPI == 6 || EPI == 9;                    // column sums of the output
+    constexpr bool QOUT = EPI == 8 || EPI == 9;                  // fp8 copy of the output (8: e4m3 behind the ReLU, 9: e5m2, signed)
+    constexpr float QMAX = EPI == 9 ? 57344.f : 448.f;    // interior tiles only: the host picks EPI 6 only when every tile is one
     unsigned char* const e_bout = (GEN || EPI == 2 || EPI == 8) ? p.bits_out : nullptr;
     const int e_dbg = GEN ? p.dbg : 0;
     unsigned long long* const e_stamps = GEN ? p.stamps : nullptr;
@@ -253,13 +257,13 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     // other slot, one entry per workgroup (zeroed here by its first wave, raised by all eight at the end of the launch)
     float q_sc = 1.f, q_m = 0.f;
     float* q_next = nullptr;
-    if constexpr (EPI == 8) {
+    if constexpr (QOUT) {
         const int parity = (int)(p.q_step[2] & 1u);
         const float* prev = p.q_parts2 + (parity ^ 1) * 256;
         q_next = p.q_parts2 + parity * 256;
         float am = fmaxf(fmaxf(prev[lane], prev[64 + lane]), fmaxf(prev[128 + lane], prev[192 + lane]));
         am = wave_max(am);
-        q_sc = am > 0.f ? 448.f / am : 1.f;                   // (fp8_scale_of, e4m3)
+        q_sc = am > 0.f ? QMAX / am : 1.f;                    // (fp8_scale_of)
         if (wave == 0 && lane == 0) {
             q_next[blockIdx.x] = 0.f;
             if (blockIdx.x == 0) p.q_scale_inv[0] = 1.f / q_sc;
@@ -299,13 +303,13 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     // so a flush is four DPP steps inside the 16-lane row and lanes 0 / 16 / 32 / 48 write one partial row.  When all tiles
     // of a workgroup lie in one column block (cs_accum, decided on the host) the flush happens once per launch instead of
     // once per tile: the DPP steps of four tiles cost the dX GEMM of FeedForward 3 us of VALU time with no MFMA beside it.
-    float cs_acc[EPI == 6 ? NJ / 2 : 1][8];
+    float cs_acc[CS ? NJ / 2 : 1][8];
 #pragma unroll
-    for (int q = 0; q < (EPI == 6 ? NJ / 2 : 1); ++q)
+    for (int q = 0; q < (CS ? NJ / 2 : 1); ++q)
 #pragma unroll
         for (int e = 0; e < 8; ++e) cs_acc[q][e] = 0.f;
     auto cs_flush = [&](int part_row, int n0) {
-        if constexpr (EPI == 6) {
+        if constexpr (CS) {
 #pragma unroll
             for (int q = 0; q < NJ / 2; ++q) {
                 float c8[8];
@@ -528,13 +532,20 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                     for (int e = 0; e < 8; ++e) bm |= (v[e] > 0.f ? 1u : 0u) << e;
                     e_bout[((((int64_t)tile * 8 + wave) * (NJ / 2) + q) * 2 + i) * 64 + lane] = (unsigned char)bm;
                 }
-                if constexpr (EPI == 8) {                     // v >= 0 behind the ReLU: |v| = v, only the upper clamp matters
+                if constexpr (QOUT) {
                     float w8[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { q_m = fmaxf(q_m, v[e]); w8[e] = fminf(v[e] * q_sc, 448.f); }
                     int lo = 0, hi = 0;
-                    lo = __builtin_amdgcn_cvt_pk_fp8_f32(w8[0], w8[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(w8[2], w8[3], lo, true);
-                    hi = __builtin_amdgcn_cvt_pk_fp8_f32(w8[4], w8[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(w8[6], w8[7], hi, true);
+                    if constexpr (EPI == 8) {                 // v >= 0 behind the ReLU: |v| = v, only the upper clamp matters
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { q_m = fmaxf(q_m, v[e]); w8[e] = fminf(v[e] * q_sc, QMAX); }
+                        lo = __builtin_amdgcn_cvt_pk_fp8_f32(w8[0], w8[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(w8[2], w8[3], lo, true);
+                        hi = __builtin_amdgcn_cvt_pk_fp8_f32(w8[4], w8[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(w8[6], w8[7], hi, true);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { q_m = fmaxf(q_m, fabsf(v[e])); w8[e] = fminf(fmaxf(v[e] * q_sc, -QMAX), QMAX); }
+                        lo = __builtin_amdgcn_cvt_pk_bf8_f32(w8[0], w8[1], lo, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(w8[2], w8[3], lo, true);
+                        hi = __builtin_amdgcn_cvt_pk_bf8_f32(w8[4], w8[5], hi, false); hi = __builtin_amdgcn_cvt_pk_bf8_f32(w8[6], w8[7], hi, true);
+                    }
                     typedef int i32x2 __attribute__((ext_vector_type(2)));
                     *(i32x2*)(p.q8 + (int64_t)row * p.ldq8 + col) = (i32x2){lo, hi};
                 }
@@ -548,13 +559,13 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
                     *(bf16x8*)cp = o;
                 }
-                if constexpr (EPI == 6) {
+                if constexpr (CS) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) cs_acc[q][e] += v[e];
                 }
             }
         }
-        if constexpr (EPI == 6) {
+        if constexpr (CS) {
             if (!p.cs_accum) cs_flush((m0 >> 5) + wm, n0);
         }
     };
@@ -604,12 +615,12 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
         stamp();
         if (++kt == nk) { finish_tile(tile_i); kt = 0; ++tile_i; stamp(); }
     }
-    if constexpr (EPI == 8) {
+    if constexpr (QOUT) {
         q_m = wave_max(q_m);
         // non-negative floats order like their bit patterns
         if (lane == 0) __hip_atomic_fetch_max((unsigned*)(q_next + blockIdx.x), __builtin_bit_cast(unsigned, q_m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if constexpr (EPI == 6) {
+    if constexpr (CS) {
         if (p.cs_accum && total > 0) {
             // rank of this workgroup among those whose tiles lie in the same column block (see dg_gemm_nt_colsum_rows)
             const int tile0 = dg_xcd_remap((int)blockIdx.x, p.n_tiles);

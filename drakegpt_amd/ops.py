@@ -216,7 +216,7 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
             sign_bits: Optional[Tensor] = None, colsum_part: Optional[Tensor] = None,
             scale_a: Optional[Tensor] = None, scale_b: Optional[Tensor] = None, fp8_out=None) -> Tensor:
     """out[M,N] = epilogue(A[M,K] @ Bm[N,K]^T).  A/Bm may carry padding columns beyond K (ld > K).
-    fp8_out: (q8 [M, N] float8_e4m3fn, parts2 fp32 [2 * FP8_AMAX_PARTS], step_state, scale_inv fp32 [1]) -- the epilogue also
+    fp8_out: (q8 [M, N] float8_e4m3fn -- float8_e5m2 in the dX direction --, parts2 fp32 [2 * FP8_AMAX_PARTS], step_state, scale_inv fp32 [1]) -- the epilogue also
     writes the output as e4m3 with delayed scaling (what fp8_quantize_delayed would make of it); only where
     gemm_nt_fp8_out_supported(M, N, K).
     fp8: A float8_e4m3fn (activations) or float8_e5m2 (gradients), Bm float8_e4m3fn, scale_a / scale_b the device scalars
@@ -275,7 +275,7 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
         a.colsum_part, a.colsum_ld, a.colsum_rows = _p(colsum_part), _ld(colsum_part), colsum_part.shape[0]
     if fp8_out is not None:
         q8, parts2, step_state, q_scale_inv = fp8_out
-        _chk(q8, "fp8_out", torch.float8_e4m3fn, contiguous=False)
+        _chk(q8, "fp8_out", torch.float8_e5m2 if A.dtype == torch.float8_e5m2 else torch.float8_e4m3fn, contiguous=False)
         _chk(parts2, "fp8_out parts2", torch.float32)
         _chk(q_scale_inv, "fp8_out scale_inv", torch.float32)
         if q8.shape != (M, N) or parts2.numel() < 2 * FP8_AMAX_PARTS:
@@ -286,14 +286,19 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
     return out
 
 
-def gemm_nt_fp8_out_supported(M: int, N: int, K: int) -> bool:
-    """can the bias + ReLU + sign-bit form of dg_gemm_nt on e4m3 operands also emit its output as e4m3 (fp8_out)?"""
+def gemm_nt_fp8_out_supported(M: int, N: int, K: int, grad: bool = False) -> bool:
+    """can dg_gemm_nt also emit its output as fp8 (fp8_out)?  grad = False: the bias + ReLU + sign-bit form on e4m3 operands
+    (e4m3 copy); grad = True: the sign-bit-masked dX form with column sums on e5m2 gradients (e5m2 copy)"""
     a = GemmNtArgs()
     a.M, a.N, a.K = M, N, K
-    a.in_dtype, a.out_dtype = dt_code(torch.float8_e4m3fn), dt_code(torch.bfloat16)
+    a.in_dtype, a.out_dtype = dt_code(torch.float8_e5m2 if grad else torch.float8_e4m3fn), dt_code(torch.bfloat16)
     a.ldc = N
-    a.C = a.bias = a.sign_bits_out = 16        # any non-null, aligned pointer value: the query only looks at which operands are present
-    a.relu = 1
+    a.C = 16                                   # any non-null, aligned pointer value: the query only looks at which operands are present
+    if grad:
+        a.sign_bits = a.colsum_part = 16
+    else:
+        a.bias = a.sign_bits_out = 16
+        a.relu = 1
     return bool(lib.dg_gemm_nt_fp8_out_supported(C.byref(a)))
 
 

@@ -202,25 +202,25 @@ def linear_nt(run: Run, x: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: 
     return ops.gemm_nt(x, run.weights.fwd(W), out_dtype, **epi)
 
 
-def _fused_fp8_out(run: Run, site: str, M: int, N: int, K: int, dev):
+def _fused_fp8_out(run: Run, site: str, M: int, N: int, K: int, dev, grad: bool = False):
     """fp8_out argument for the GEMM that PRODUCES the operand of call site `site` (training engine, history seeded): the e4m3
     copy leaves that GEMM's epilogue and the site's cast launch -- which would re-read the whole tensor -- disappears"""
     if not run.fp8 or run.fp8_sites is None or run.fp8_seed or site not in run.fp8_sites or run.step_word is None:
         return None
-    if not (fp8_k_ok(K) and fp8_k_ok(N) and ops.gemm_nt_fp8_out_supported(M, N, K)):
+    if not (fp8_k_ok(K) and fp8_k_ok(N) and ops.gemm_nt_fp8_out_supported(M, N, K, grad=grad)):
         return None
-    return (torch.empty((M, N), dtype=E4M3, device=dev), run.fp8_sites[site], run.step_word,
+    return (torch.empty((M, N), dtype=E5M2 if grad else E4M3, device=dev), run.fp8_sites[site], run.step_word,
             torch.empty((1,), dtype=torch.float32, device=dev))
 
 
-def linear_dx(run: Run, g: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: Optional[str] = None, **epi) -> Tensor:
-    """dX of a block Linear: epilogue(g W), g [M, out] in the activation dtype (a gradient: e5m2 in fp8 mode), W^T shadow
-    [in, out padded]"""
+def linear_dx(run: Run, g: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: Optional[str] = None, g8=None, **epi) -> Tensor:
+    """dX of a block Linear: epilogue(g W), g [M, out] in the activation dtype (a gradient: e5m2 in fp8 mode -- quantised here,
+    or already by the epilogue that produced it: g8 = (e5m2 copy, scale)), W^T shadow [in, out padded]"""
     K = W.shape[0]
     if run.fp8 and fp8_k_ok(K) and g.is_contiguous() and g.dtype == torch.bfloat16 and g.shape[1] == K:
         wq, ws = run.weights.bwd8(W)
         if wq.shape[1] == K:
-            gq, gs = _quantize_operand(run, g, E5M2, fp8_site)
+            gq, gs = g8 if g8 is not None else _quantize_operand(run, g, E5M2, fp8_site)
             return ops.gemm_nt(gq, wq, out_dtype, K=K, scale_a=gs, scale_b=ws, **epi)
     return ops.gemm_nt(g, run.weights.bwd(W), out_dtype, K=K, **epi)
 
@@ -358,9 +358,13 @@ def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2:
             rows = ops.gemm_nt_colsum_rows(run.act, g.shape[0], w1.shape[0], w2.shape[0], in_dtype=_op_dtype(run, w2.shape[0], grad=True))
             if rows:
                 cs_part = vector_rows(keys["b1"], w1.shape[0], rows)
+        df8 = None
         if cs_part is not None:
-            # the b1 gradient (column sums of df) leaves the dX GEMM's epilogue as partial rows
-            df = linear_dx(run, g, w2, run.act, fp8_site=f"{layer}.g_ffn", sign_bits=bits, colsum_part=cs_part)
+            # the b1 gradient (column sums of df) leaves the dX GEMM's epilogue as partial rows -- and, in fp8 mode, df itself a
+            # second time as the e5m2 operand of the first Linear's dX GEMM below
+            if need_dx:
+                df8 = _fused_fp8_out(run, f"{layer}.df", g.shape[0], w1.shape[0], w2.shape[0], g.device, grad=True)
+            df = linear_dx(run, g, w2, run.act, fp8_site=f"{layer}.g_ffn", sign_bits=bits, colsum_part=cs_part, fp8_out=df8)
         else:
             if bits is not None:
                 df = linear_dx(run, g, w2, run.act, fp8_site=f"{layer}.g_ffn", sign_bits=bits)
@@ -371,11 +375,12 @@ def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2:
     weight_grad(sink, keys["w1"], df, h, w1.shape[0], w1.shape[1])
     if not need_dx:
         return None
+    d8 = (df8[0], df8[3]) if (w2 is not None and df8 is not None) else None
     if ln_w is not None:
-        dh = linear_dx(run, df, w1, _dh_dtype(run, ln_w), fp8_site=f"{layer}.df")
+        dh = linear_dx(run, df, w1, _dh_dtype(run, ln_w), fp8_site=f"{layer}.df", g8=d8)
         dx, g_next = _ln_tail(run, dh, x2d, ln_w, mean, rstd, dy if residual else None, sink, keys, emit)
         return (dx, g_next) if emit is not None else dx
-    dx = linear_dx(run, df, w1, torch.float32, fp8_site=f"{layer}.df", residual=dy if residual else None)
+    dx = linear_dx(run, df, w1, torch.float32, fp8_site=f"{layer}.df", g8=d8, residual=dy if residual else None)
     return (dx, None) if emit is not None else dx
 
 
