@@ -118,6 +118,9 @@ extern "C" int dg_layernorm_fwd(const float* x, const float* gamma, const float*
 // (that sub-layer's bias gradient).  Saves one 38 MB pass and one launch per sub-layer.
 struct LnFuse {
     void* g; float* gbias_part; float inv_keep; uint32_t thr; int drop; const uint32_t* rng; uint32_t site;
+    // fp8 mode (nullable): g a second time as e5m2 with delayed scaling -- the operand of the dX GEMM that runs next -- in
+    // dg_fp8_quantize_delayed's protocol: the launch has exactly 256 workgroups, each leaves ONE partial maximum (plain store)
+    unsigned char* g8; float* q_parts2; const uint32_t* q_step; float* q_scale_inv;
 };
 // TR: type of the residual-branch gradient stream (dresid in, dx out): float, or bf16 on the vector path -- the engine's bf16 /
 // fp8 modes keep the stream in bf16 (it is rounded once per sub-layer, like every other activation gradient of those modes):
@@ -148,6 +151,17 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
         }
         uint32_t fkey = 0;
         if (FUSE_G && fz.drop) fkey = dg_site_key_dev(fz.rng, fz.site);
+        float q_sc = 1.f, q_m = 0.f;
+        float* q_next = nullptr;
+        if (FUSE_G == 1 && fz.g8) {                     // (uniform)
+            const int parity = (int)(fz.q_step[2] & 1u);
+            const float* prev = fz.q_parts2 + (parity ^ 1) * 256;
+            q_next = fz.q_parts2 + parity * 256;
+            float am = fmaxf(fmaxf(prev[lane], prev[64 + lane]), fmaxf(prev[128 + lane], prev[192 + lane]));
+            am = wave_max(am);
+            q_sc = am > 0.f ? 57344.f / am : 1.f;
+            if (blockIdx.x == 0 && threadIdx.x == 0) fz.q_scale_inv[0] = 1.f / q_sc;
+        }
         for (int row = m_begin + w; row < m_end; row += NW) {
             const float mu = mean[row], rs = rstd[row];
             typedef TD TD4 __attribute__((ext_vector_type(4)));
@@ -211,6 +225,15 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
 #pragma unroll
                             for (int j = 0; j < 4; ++j) t[j] = (bf16_t)gq[j];
                             *(bf16x4*)((bf16_t*)fz.g + (int64_t)row * C + i * 4) = t;
+                            if (fz.g8) {                // (uniform)
+                                float w4[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { q_m = fmaxf(q_m, fabsf(gq[j])); w4[j] = fminf(fmaxf(gq[j] * q_sc, -57344.f), 57344.f); }
+                                int wq = 0;
+                                wq = __builtin_amdgcn_cvt_pk_bf8_f32(w4[0], w4[1], wq, false);
+                                wq = __builtin_amdgcn_cvt_pk_bf8_f32(w4[2], w4[3], wq, true);
+                                *(int*)(fz.g8 + (int64_t)row * C + i * 4) = wq;
+                            }
                         } else {
                             *(f32x4*)((float*)fz.g + (int64_t)row * C + i * 4) = gq;
                         }
@@ -239,6 +262,17 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
         combine(dg, dgamma_part);
         combine(db, dbeta_part);
         if (FUSE_G && fz.gbias_part) combine(gb, fz.gbias_part);       // (uniform)
+        if (FUSE_G == 1 && fz.g8) {                                    // (uniform) this workgroup's maximum -> its own entry
+            q_m = wave_max(q_m);
+            if (lane == 0) lx[w] = q_m;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float mm = 0.f;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) mm = fmaxf(mm, lx[k]);
+                q_next[blockIdx.x] = mm;
+            }
+        }
     } else {
         // generic path: any C; column partials accumulate directly in LDS [2][NW][C] per wave
         float* lg = lds; float* lb = lds + NW * C;
@@ -345,6 +379,26 @@ extern "C" int dg_layernorm_bwd_fused(const void* dy, int dy_dtype, const float*
     fz.inv_keep = 1.f / (1.f - dropout_p);
     fz.thr = dg_drop_threshold(dropout_p);
     fz.rng = rng_state; fz.site = site;
+    fz.g8 = nullptr; fz.q_parts2 = nullptr; fz.q_step = nullptr; fz.q_scale_inv = nullptr;
     return ln_bwd_launch(fz, g_dtype == DG_BF16 ? 1 : 2, dy, dy_dtype, x, gamma, mean, rstd, dresid, dx, resid_dtype, dgamma_part, dbeta_part,
+                         part_stride, n_partials, M, C, stream);
+}
+
+extern "C" int dg_layernorm_bwd_fused_fp8(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
+                                          const float* rstd, const void* dresid, void* dx, int resid_dtype,
+                                          float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
+                                          int M, int C,
+                                          void* g, float dropout_p, const uint32_t* rng_state, uint32_t site, float* gbias_part,
+                                          void* g8, float* g8_parts2, const uint32_t* step_state, float* g8_scale_inv, void* stream) {
+    if (dropout_p < 0.f || dropout_p >= 1.f) return DG_ERR_ARG;
+    if (!g8 || !g8_parts2 || !step_state || !g8_scale_inv || n_partials != DG_FP8_AMAX_PARTS || C % 4 || (((uintptr_t)g8) & 3)) return DG_ERR_ARG;
+    LnFuse fz;
+    fz.g = g; fz.gbias_part = gbias_part;
+    fz.drop = (dropout_p > 0.f && rng_state) ? 1 : 0;
+    fz.inv_keep = 1.f / (1.f - dropout_p);
+    fz.thr = dg_drop_threshold(dropout_p);
+    fz.rng = rng_state; fz.site = site;
+    fz.g8 = (unsigned char*)g8; fz.q_parts2 = g8_parts2; fz.q_step = step_state; fz.q_scale_inv = g8_scale_inv;
+    return ln_bwd_launch(fz, 1, dy, dy_dtype, x, gamma, mean, rstd, dresid, dx, resid_dtype, dgamma_part, dbeta_part,
                          part_stride, n_partials, M, C, stream);
 }

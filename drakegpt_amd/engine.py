@@ -520,11 +520,11 @@ class TrainEngine:
             sa, sf = saved[l]
             dh, g_next = S.ffn_bwd(run, sf, dh, P["ln2w"], P["w1"], P["w2"], True, p, l, sink,
                                    {"w1": f"{l}.w1", "b1": f"{l}.b1", "w2": f"{l}.w2", "b2": f"{l}.b2", "ln_w": f"{l}.ln2w", "ln_b": f"{l}.ln2b"},
-                                   g_in=g_next, emit=(p, S.site_proj(l), f"{l}.bproj", self.C))
+                                   g_in=g_next, emit=(p, S.site_proj(l), f"{l}.bproj", self.C, f"{l}.g_proj"))
             keys = {"wqkv": f"{l}.wqkv", "wproj": f"{l}.wproj", "bproj": f"{l}.bproj", "ln_w": f"{l}.ln1w", "ln_b": f"{l}.ln1b"}
             if l > 0:
                 dh, g_next = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink, keys,
-                                        g_in=g_next, emit=(p, S.site_ffn(l - 1), f"{l - 1}.b2", self.C))
+                                        g_in=g_next, emit=(p, S.site_ffn(l - 1), f"{l - 1}.b2", self.C, f"{l - 1}.g_ffn"))
             elif self.onehot is not None:
                 # first block: also take dx in bf16 (no dropout, no bias behind it) -- the X operand of the token-table problem
                 dh, st["g0"] = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink, keys,

@@ -188,9 +188,11 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
 def layernorm_bwd_fused(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dresid: Optional[Tensor],
                         dgamma_part: Tensor, dbeta_part: Tensor, part_stride: int, n_partials: int,
                         g_dtype: torch.dtype, p: float, rng_state: Optional[Tensor], site: int, gbias_part: Optional[Tensor],
-                        stream_dtype: torch.dtype = torch.float32):
+                        stream_dtype: torch.dtype = torch.float32, fp8_out=None):
     """layernorm_bwd that also emits g = dropout_bwd(dx) in g_dtype and its column-sum partials; returns (dx, g).
-    stream_dtype: type of dresid (in) and dx (out), fp32 or bf16 (the engine's bf16 gradient stream: bf16 dy and g only)."""
+    stream_dtype: type of dresid (in) and dx (out), fp32 or bf16 (the engine's bf16 gradient stream: bf16 dy and g only).
+    fp8_out = (parts2 fp32 [2 * FP8_AMAX_PARTS], step_state): g (bf16) also leaves as e5m2 with delayed scaling -- the operand of
+    the fp8 dX GEMM that runs next; n_partials must be FP8_AMAX_PARTS.  Returns (dx, g, g8, scale_inv [1]) then."""
     _chk(dy, "dy")
     _chk(x, "x", torch.float32)
     if dresid is not None:
@@ -199,6 +201,19 @@ def layernorm_bwd_fused(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd
     M = x.numel() // Cd
     dx = torch.empty(x.shape, dtype=stream_dtype, device=x.device)
     g = torch.empty(x.shape, dtype=g_dtype, device=x.device)
+    if fp8_out is not None:
+        parts2, step_state = fp8_out
+        _chk(parts2, "fp8_out parts2", torch.float32)
+        _chk(step_state, "fp8_out step_state", torch.int32)
+        if g_dtype != torch.bfloat16 or parts2.numel() != 2 * FP8_AMAX_PARTS or n_partials != FP8_AMAX_PARTS:
+            raise RuntimeError("layernorm_bwd_fused: fp8_out needs a bf16 g, a [2 * FP8_AMAX_PARTS] history and n_partials == FP8_AMAX_PARTS")
+        g8 = torch.empty(x.shape, dtype=torch.float8_e5m2, device=x.device)
+        sinv = torch.empty((1,), dtype=torch.float32, device=x.device)
+        check(lib.dg_layernorm_bwd_fused_fp8(_p(dy), dt_code(dy.dtype), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dresid), _p(dx), dt_code(stream_dtype),
+                                             _p(dgamma_part), _p(dbeta_part), part_stride, n_partials, M, Cd, _p(g), float(p),
+                                             _p(rng_state) if p > 0.0 else None, site, _p(gbias_part), _p(g8), _p(parts2), _p(step_state), _p(sinv),
+                                             _stream()), "dg_layernorm_bwd_fused_fp8")
+        return dx, g, g8, sinv
     check(lib.dg_layernorm_bwd_fused(_p(dy), dt_code(dy.dtype), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dresid), _p(dx), dt_code(stream_dtype), _p(dgamma_part),
                                      _p(dbeta_part), part_stride, n_partials, M, Cd, _p(g), dt_code(g_dtype), float(p),
                                      _p(rng_state) if p > 0.0 else None, site, _p(gbias_part), _stream()), "dg_layernorm_bwd_fused")

@@ -17,6 +17,8 @@ Reference call sites restated here (paths relative to the reference repository r
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -72,6 +74,9 @@ def splits_for_matrix(P: int, Q: int, rows: int, s_max: int, device=None) -> int
         _NCU[key] = torch.cuda.get_device_properties(device).multi_processor_count if torch.cuda.is_available() else 256
     tiles = ((P + 127) // 128) * ((Q + 127) // 128)
     return max(1, min(s_max, _NCU[key] // tiles, max(1, rows // 256)))
+
+
+FUSED_LN_FP8 = os.environ.get("DG_FP8_FUSED_LN", "1") != "0"      # fp8 mode: the fused LayerNorm backward also emits the e5m2 operand (A/B switch)
 
 
 def n_partials_for(rows: int) -> int:
@@ -220,6 +225,8 @@ def linear_dx(run: Run, g: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: 
     if run.fp8 and fp8_k_ok(K) and g.is_contiguous() and g.dtype == torch.bfloat16 and g.shape[1] == K:
         wq, ws = run.weights.bwd8(W)
         if wq.shape[1] == K:
+            if g8 is None:
+                g8 = getattr(g, "dg_fp8", None)         # left by the fused LayerNorm backward that produced g (see _ln_tail)
             gq, gs = g8 if g8 is not None else _quantize_operand(run, g, E5M2, fp8_site)
             return ops.gemm_nt(gq, wq, out_dtype, K=K, scale_a=gs, scale_b=ws, **epi)
     return ops.gemm_nt(g, run.weights.bwd(W), out_dtype, K=K, **epi)
@@ -244,13 +251,22 @@ def _dh_dtype(run: Run, ln_w: Tensor) -> torch.dtype:
 
 
 def _ln_tail(run: Run, dh: Tensor, x2d: Tensor, ln_w: Tensor, mean, rstd, dresid, sink, keys, emit):
-    """LayerNorm backward (+ residual-branch gradient).  With `emit = (p, site, bias_key, N)` the kernel also
-    produces g = dropout_bwd(dx) for the sub-layer that runs next in backward, and that sub-layer's bias partials."""
+    """LayerNorm backward (+ residual-branch gradient).  With `emit = (p, site, bias_key, N[, fp8_site])` the kernel also
+    produces g = dropout_bwd(dx) for the sub-layer that runs next in backward, and that sub-layer's bias partials; in fp8
+    training (history of call site `fp8_site` seeded) g leaves a second time as the e5m2 operand of that sub-layer's dX GEMM
+    and travels with g as its attribute `dg_fp8` = (e5m2 copy, scale) -- linear_dx picks it up instead of casting."""
     pg, sg, ng = sink.vector(keys["ln_w"], ln_w.numel())
     pb, _, _ = sink.vector(keys["ln_b"], ln_w.numel())
     if emit is not None and ops.layernorm_bwd_fused_supported(ln_w.numel()):
-        p, site, bias_key, N = emit
+        p, site, bias_key, N = emit[:4]
+        f8site = emit[4] if len(emit) > 4 else None
         pq = sink.vector(bias_key, N)[0] if bias_key is not None else None       # None: g only (no sub-layer bias behind it)
+        if (f8site is not None and run.fp8 and run.fp8_sites is not None and not run.fp8_seed and f8site in run.fp8_sites
+                and run.step_word is not None and run.act == torch.bfloat16 and ng == ops.FP8_AMAX_PARTS and fp8_k_ok(N) and FUSED_LN_FP8):
+            dx, g, g8, gs = ops.layernorm_bwd_fused(dh, x2d, ln_w, mean, rstd, dresid, pg, pb, sg, ng, run.act, run.p(p), run.rng, site, pq,
+                                                    stream_dtype=run.stream, fp8_out=(run.fp8_sites[f8site], run.step_word))
+            g.dg_fp8 = (g8, gs)
+            return dx, g
         return ops.layernorm_bwd_fused(dh, x2d, ln_w, mean, rstd, dresid, pg, pb, sg, ng, run.act, run.p(p), run.rng, site, pq,
                                        stream_dtype=run.stream)
     if run.stream != torch.float32:

@@ -45,7 +45,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 11   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 12   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -112,6 +112,15 @@ int dg_layernorm_bwd_fused(const void* dy, int dy_dtype, const float* x, const f
                            int M, int C,
                            void* g, int g_dtype, float dropout_p, const uint32_t* rng_state, uint32_t site,
                            float* gbias_part, void* stream);
+/* fp8 mode: the same with g in bf16 AND a second time as OCP e5m2 (g8 [M][C] bytes: the gradient operand of the dX GEMM that
+ * runs next) with delayed per-tensor scaling as in dg_fp8_quantize_delayed (g8_parts2 [2][DG_FP8_AMAX_PARTS], step_state,
+ * *g8_scale_inv).  n_partials must be DG_FP8_AMAX_PARTS: every workgroup leaves one partial maximum. */
+int dg_layernorm_bwd_fused_fp8(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
+                               const float* rstd, const void* dresid, void* dx, int resid_dtype,
+                               float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
+                               int M, int C,
+                               void* g, float dropout_p, const uint32_t* rng_state, uint32_t site, float* gbias_part,
+                               void* g8, float* g8_parts2, const uint32_t* step_state, float* g8_scale_inv, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * GEMM "NT": C[M,N] = epilogue(A[M,K] . B[N,K]^T), MFMA with fp32 accumulation.

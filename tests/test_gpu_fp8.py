@@ -251,6 +251,52 @@ def test_gemm_nt_fp8_out_dx_form(dev, M, N, K):
     assert parts2[3].item() == pytest.approx(amax_prev)
 
 
+@pytest.mark.parametrize("M,C", [(8192, 1024), (16384, 384), (3000, 768)])
+def test_layernorm_bwd_fused_fp8_emits_the_next_gradient_operand(dev, M, C):
+    """the fused LayerNorm backward of the bf16 gradient stream also leaves g = dropout_bwd(dx) as e5m2 with delayed scaling
+    (the operand of the fp8 dX GEMM that runs next): dx, g and every partial row bit-identical to the call without fp8_out;
+    g8 = e5m2(g * 57344 / amax_prev) of the unrounded g; one partial maximum per workgroup (exactly 256 of them)"""
+    from oracle import rng_ref
+    from drakegpt_amd import ops
+    G, site, seed, step, p = ops.FP8_AMAX_PARTS, 5, 11, 8, 0.2
+    gen = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=gen)
+    w, b = torch.randn(C, generator=gen), torch.randn(C, generator=gen)
+    dy = torch.randn(M, C, generator=gen).bfloat16()
+    dres = torch.randn(M, C, generator=gen).bfloat16()
+    d = lambda t: t.to(dev)
+    _, mean, rstd = ops.layernorm_fwd(d(x), d(w), d(b), torch.float32)
+    rng = ops.new_rng_state(seed, dev, step)
+    P0 = [torch.full((G, C), float("nan"), device=dev) for _ in range(3)]
+    dx0, g0 = ops.layernorm_bwd_fused(d(dy), d(x), d(w), mean, rstd, d(dres), P0[0], P0[1], C, G, torch.bfloat16, p, rng, site, P0[2], stream_dtype=torch.bfloat16)
+    xd = x.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xd, (C,), w.double(), b.double(), 1e-5).backward(dy.double())
+    keep = torch.from_numpy(rng_ref.keep_mask(seed, step, site, p, M * C).reshape(M, C)).double()
+    g_ref = (xd.grad + dres.double()) * keep / (1.0 - p)
+    gmax = g_ref.abs().max().item()
+    P = ops.FP8_AMAX_PARTS
+    parts2 = torch.zeros(2 * P, device=dev)
+    amax_prev = 0.8 * gmax
+    parts2[P:] = amax_prev * torch.rand(P, generator=gen).to(dev)            # step 8 is even: slot 1 read, slot 0 written
+    parts2[P + 9] = amax_prev
+    parts2[:P] = 321.0
+    P1 = [torch.full((G, C), float("nan"), device=dev) for _ in range(3)]
+    dx, g, g8, sinv = ops.layernorm_bwd_fused(d(dy), d(x), d(w), mean, rstd, d(dres), P1[0], P1[1], C, G, torch.bfloat16, p, rng, site, P1[2],
+                                               stream_dtype=torch.bfloat16, fp8_out=(parts2, rng))
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx0) and torch.equal(g, g0) and all(torch.equal(a, b_) for a, b_ in zip(P0, P1))
+    assert g8.dtype == E5 and abs(sinv.item() - amax_prev / 57344.0) < 1e-6 * amax_prev
+    got = g8.float().double().cpu() * sinv.item()
+    want = g_ref.clamp(min=-amax_prev, max=amax_prev)
+    tol = want.abs() * (2.0 ** -3 + 1e-4) + amax_prev / 57344.0 * 2.0 ** -16 + 2e-6 * gmax
+    assert ((got - want).abs() <= tol).all()
+    assert torch.all(got[keep == 0] == 0)
+    assert abs(parts2[:P].max().item() - gmax) < 1e-5 * gmax and parts2[:P].min().item() >= 0 and parts2[P + 9].item() == pytest.approx(amax_prev)
+    with pytest.raises(RuntimeError):                                        # one partial maximum per workgroup: exactly 256
+        ops.layernorm_bwd_fused(d(dy), d(x), d(w), mean, rstd, d(dres), P1[0][:24], P1[1][:24], C, 24, torch.bfloat16, p, rng, site, P1[2][:24],
+                                stream_dtype=torch.bfloat16, fp8_out=(parts2, rng))
+
+
 def test_gemm_nt_fp8_argument_validation(dev):
     from drakegpt_amd import ops
     A = torch.zeros(128, 256, dtype=E4, device=dev)
