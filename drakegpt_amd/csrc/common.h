@@ -80,6 +80,24 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// |x| maxima for the fp8 scales that do NOT lose a NaN / Inf: non-negative floats order like their bit patterns and
+// every NaN pattern lies above +Inf, so an unsigned integer max keeps the worst element where fmaxf would drop it.  A poisoned
+// maximum makes the scale NaN (dg_fp8_scale_of), the casts keep a NaN element NaN (dg_fp8_clamp compares, it does not min / max),
+// so a diverging fp8 run shows up as a NaN loss instead of training on saturated values.
+__device__ __forceinline__ float dg_amax_nan(float m, float x) {
+    const uint32_t a = __builtin_bit_cast(uint32_t, m), b = __builtin_bit_cast(uint32_t, x) & 0x7FFFFFFFu;
+    return __builtin_bit_cast(float, a > b ? a : b);
+}
+__device__ __forceinline__ float wave_amax_nan(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = dg_amax_nan(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float dg_fp8_scale_of(float amax, float fmax) {      // amax == 0: scale 1; NaN / Inf amax: NaN
+    return amax == 0.f ? 1.f : (amax < __builtin_inff() ? fmax / amax : __builtin_nanf(""));
+}
+__device__ __forceinline__ float dg_fp8_clamp(float w, float fmax) { return w > fmax ? fmax : (w < -fmax ? -fmax : w); }   // NaN stays NaN
+
 // ---------------------------------------------------------------------------------------------
 // typed load/store of one element as float
 template <typename T> __device__ __forceinline__ float to_f32(T v);

@@ -153,7 +153,9 @@ __global__ __launch_bounds__(CEF_THREADS) void cross_entropy_small_fused_kernel(
 #pragma unroll 8
         for (int r = 0; r < CEF_RG; ++r) b += lred[r];
         __hip_atomic_store(fz.loss_part + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the share has left this wave before the counter moves
+        // the share must be ACKNOWLEDGED by L2 before the counter moves: a workgroup-scope release does not wait on vmcnt on gfx9
+        // (no tgsplit), and an agent-scope release would write the whole L2 back; the explicit wait is what the dW hand-over uses
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned prev = __hip_atomic_fetch_add(fz.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = prev == gridDim.x - 1 ? 1u : 0u;
     }

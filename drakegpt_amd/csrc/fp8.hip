@@ -27,13 +27,13 @@ __global__ __launch_bounds__(256) void fp8_amax_kernel(const T* __restrict__ x, 
     for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < nv; i += (int64_t)DG_FP8_AMAX_PARTS * 256) {
         const TV v = xv[i];
 #pragma unroll
-        for (int e = 0; e < V; ++e) m = fmaxf(m, fabsf((float)v[e]));
+        for (int e = 0; e < V; ++e) m = dg_amax_nan(m, (float)v[e]);
     }
-    for (int64_t i = nv * V + (int64_t)b * 256 + threadIdx.x; i < len; i += (int64_t)DG_FP8_AMAX_PARTS * 256) m = fmaxf(m, fabsf((float)x[first + i]));
-    m = wave_max(m);
+    for (int64_t i = nv * V + (int64_t)b * 256 + threadIdx.x; i < len; i += (int64_t)DG_FP8_AMAX_PARTS * 256) m = dg_amax_nan(m, (float)x[first + i]);
+    m = wave_amax_nan(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) parts[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0) parts[blockIdx.x] = dg_amax_nan(dg_amax_nan(red[0], red[1]), dg_amax_nan(red[2], red[3]));
 }
 
 extern "C" int dg_fp8_amax(const void* x, int dtype, int64_t n, const int64_t* seg, int n_seg, float* amax_parts, void* stream) {
@@ -51,7 +51,6 @@ extern "C" int dg_fp8_amax(const void* x, int dtype, int64_t n, const int64_t* s
 // ---------------------------------------------------------------------------------------------
 // q = cvt(clamp(x * scale)), scale = FMAX / amax (amax == 0: scale 1); scale_inv[seg] = 1 / scale is written by block 0 of
 // the segment for the consumer.  Eight elements per thread: 16 B in (bf16) / 2 x 16 B (f32), 8 B out.
-__device__ __forceinline__ float fp8_scale_of(float amax, float fmax) { return amax > 0.f ? fmax / amax : 1.f; }
 
 template <typename T, bool BF8>
 __global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__ x, uint8_t* __restrict__ q, int64_t n,
@@ -64,11 +63,11 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__
     const int nb = seg ? blocks_per_seg : gridDim.x;
     const float fmax = BF8 ? FP8_E5M2_MAX : FP8_E4M3_MAX;
     // the segment's amax from its DG_FP8_AMAX_PARTS (= 256 = blockDim) partial maxima
-    float am = wave_max(parts[(int64_t)s * DG_FP8_AMAX_PARTS + threadIdx.x]);
+    float am = wave_amax_nan(parts[(int64_t)s * DG_FP8_AMAX_PARTS + threadIdx.x]);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
     __syncthreads();
-    am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float sc = fp8_scale_of(am, fmax);
+    am = dg_amax_nan(dg_amax_nan(red[0], red[1]), dg_amax_nan(red[2], red[3]));
+    const float sc = dg_fp8_scale_of(am, fmax);
     if (b == 0 && threadIdx.x == 0 && scale_inv) scale_inv[s] = 1.f / sc;
     const int64_t n8 = len / 8;
     for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < n8; i += (int64_t)nb * 256) {
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__
             for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[4 + e] = t1[e]; }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e] * sc, -fmax), fmax);
+        for (int e = 0; e < 8; ++e) v[e] = dg_fp8_clamp(v[e] * sc, fmax);
         int lo = 0, hi = 0;
         if (BF8) {
             lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], lo, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], lo, true);
@@ -138,14 +137,14 @@ __global__ __launch_bounds__(1024) void fp8_quantize_delayed_kernel(const T* __r
     float* next = parts2 + parity * DG_FP8_AMAX_PARTS;
     const float fmax = BF8 ? FP8_E5M2_MAX : FP8_E4M3_MAX;
     float am = threadIdx.x < DG_FP8_AMAX_PARTS ? prev[threadIdx.x] : 0.f;
-    am = wave_max(am);
+    am = wave_amax_nan(am);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
     __syncthreads();
     am = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) am = fmaxf(am, red[i]);
+    for (int i = 0; i < 16; ++i) am = dg_amax_nan(am, red[i]);
     __syncthreads();
-    const float sc = fp8_scale_of(am, fmax);
+    const float sc = dg_fp8_scale_of(am, fmax);
     if (blockIdx.x == 0 && threadIdx.x == 0) scale_inv[0] = 1.f / sc;
     float m = 0.f;
     const int64_t n8 = n / 8;
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(1024) void fp8_quantize_delayed_kernel(const T* __r
             for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[4 + e] = t1[e]; }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { m = fmaxf(m, fabsf(v[e])); v[e] = fminf(fmaxf(v[e] * sc, -fmax), fmax); }
+        for (int e = 0; e < 8; ++e) { m = dg_amax_nan(m, v[e]); v[e] = dg_fp8_clamp(v[e] * sc, fmax); }
         int lo = 0, hi = 0;
         if (BF8) {
             lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], lo, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], lo, true);
@@ -173,13 +172,13 @@ __global__ __launch_bounds__(1024) void fp8_quantize_delayed_kernel(const T* __r
         typedef int i32x2 __attribute__((ext_vector_type(2)));
         *(i32x2*)(q + i * 8) = (i32x2){lo, hi};
     }
-    m = wave_max(m);
+    m = wave_amax_nan(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         float mm = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mm = fmaxf(mm, red[i]);
+        for (int i = 0; i < 16; ++i) mm = dg_amax_nan(mm, red[i]);
         next[blockIdx.x] = mm;
     }
 }

@@ -261,12 +261,15 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
         const int parity = (int)(p.q_step[2] & 1u);
         const float* prev = p.q_parts2 + (parity ^ 1) * 256;
         q_next = p.q_parts2 + parity * 256;
-        float am = fmaxf(fmaxf(prev[lane], prev[64 + lane]), fmaxf(prev[128 + lane], prev[192 + lane]));
-        am = wave_max(am);
-        q_sc = am > 0.f ? QMAX / am : 1.f;                    // (fp8_scale_of)
+        float am = dg_amax_nan(dg_amax_nan(prev[lane], prev[64 + lane]), dg_amax_nan(prev[128 + lane], prev[192 + lane]));
+        am = wave_amax_nan(am);
+        q_sc = dg_fp8_scale_of(am, QMAX);
         if (wave == 0 && lane == 0) {
-            q_next[blockIdx.x] = 0.f;
+            // zeroed with an agent-scope atomic store that is acknowledged (vmcnt) before this wave reaches the first barrier:
+            // the other waves' atomic maxima at the end of the launch are then ordered behind it
+            __hip_atomic_store(q_next + blockIdx.x, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (blockIdx.x == 0) p.q_scale_inv[0] = 1.f / q_sc;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
     uint32_t key = 0;
@@ -537,12 +540,12 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                     int lo = 0, hi = 0;
                     if constexpr (EPI == 8) {                 // v >= 0 behind the ReLU: |v| = v, only the upper clamp matters
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { q_m = fmaxf(q_m, v[e]); w8[e] = fminf(v[e] * q_sc, QMAX); }
+                        for (int e = 0; e < 8; ++e) { q_m = dg_amax_nan(q_m, v[e]); const float w = v[e] * q_sc; w8[e] = w > QMAX ? QMAX : w; }
                         lo = __builtin_amdgcn_cvt_pk_fp8_f32(w8[0], w8[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(w8[2], w8[3], lo, true);
                         hi = __builtin_amdgcn_cvt_pk_fp8_f32(w8[4], w8[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(w8[6], w8[7], hi, true);
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { q_m = fmaxf(q_m, fabsf(v[e])); w8[e] = fminf(fmaxf(v[e] * q_sc, -QMAX), QMAX); }
+                        for (int e = 0; e < 8; ++e) { q_m = dg_amax_nan(q_m, v[e]); w8[e] = dg_fp8_clamp(v[e] * q_sc, QMAX); }
                         lo = __builtin_amdgcn_cvt_pk_bf8_f32(w8[0], w8[1], lo, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(w8[2], w8[3], lo, true);
                         hi = __builtin_amdgcn_cvt_pk_bf8_f32(w8[4], w8[5], hi, false); hi = __builtin_amdgcn_cvt_pk_bf8_f32(w8[6], w8[7], hi, true);
                     }
@@ -616,8 +619,8 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
         if (++kt == nk) { finish_tile(tile_i); kt = 0; ++tile_i; stamp(); }
     }
     if constexpr (QOUT) {
-        q_m = wave_max(q_m);
-        // non-negative floats order like their bit patterns
+        q_m = wave_amax_nan(q_m);
+        // non-negative floats -- and NaN patterns above them -- order like their bit patterns
         if (lane == 0) __hip_atomic_fetch_max((unsigned*)(q_next + blockIdx.x), __builtin_bit_cast(unsigned, q_m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (CS) {

@@ -157,9 +157,9 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
             const int parity = (int)(fz.q_step[2] & 1u);
             const float* prev = fz.q_parts2 + (parity ^ 1) * 256;
             q_next = fz.q_parts2 + parity * 256;
-            float am = fmaxf(fmaxf(prev[lane], prev[64 + lane]), fmaxf(prev[128 + lane], prev[192 + lane]));
-            am = wave_max(am);
-            q_sc = am > 0.f ? 57344.f / am : 1.f;
+            float am = dg_amax_nan(dg_amax_nan(prev[lane], prev[64 + lane]), dg_amax_nan(prev[128 + lane], prev[192 + lane]));
+            am = wave_amax_nan(am);
+            q_sc = dg_fp8_scale_of(am, 57344.f);
             if (blockIdx.x == 0 && threadIdx.x == 0) fz.q_scale_inv[0] = 1.f / q_sc;
         }
         for (int row = m_begin + w; row < m_end; row += NW) {
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
                             if (fz.g8) {                // (uniform)
                                 float w4[4];
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) { q_m = fmaxf(q_m, fabsf(gq[j])); w4[j] = fminf(fmaxf(gq[j] * q_sc, -57344.f), 57344.f); }
+                                for (int j = 0; j < 4; ++j) { q_m = dg_amax_nan(q_m, gq[j]); w4[j] = dg_fp8_clamp(gq[j] * q_sc, 57344.f); }
                                 int wq = 0;
                                 wq = __builtin_amdgcn_cvt_pk_bf8_f32(w4[0], w4[1], wq, false);
                                 wq = __builtin_amdgcn_cvt_pk_bf8_f32(w4[2], w4[3], wq, true);
@@ -263,13 +263,13 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
         combine(db, dbeta_part);
         if (FUSE_G && fz.gbias_part) combine(gb, fz.gbias_part);       // (uniform)
         if (FUSE_G == 1 && fz.g8) {                                    // (uniform) this workgroup's maximum -> its own entry
-            q_m = wave_max(q_m);
+            q_m = wave_amax_nan(q_m);
             if (lane == 0) lx[w] = q_m;
             __syncthreads();
             if (threadIdx.x == 0) {
                 float mm = 0.f;
 #pragma unroll
-                for (int k = 0; k < NW; ++k) mm = fmaxf(mm, lx[k]);
+                for (int k = 0; k < NW; ++k) mm = dg_amax_nan(mm, lx[k]);
                 q_next[blockIdx.x] = mm;
             }
         }

@@ -69,12 +69,18 @@ class _LM(HipModule):
     def _head(self, x):
         return HF.linear(x, self.lm_head.weight, self.lm_head.bias, self.act_dtype)
 
+    check_ids = True      # False: skip the id range check (one or two device-to-host syncs per forward that nn.Embedding does not
+                          # have) once a data source has been validated -- ids out of range are then CLAMPED by the kernels
+
     def _check_ids(self, idx, targets):
         ops._chk(idx, "idx", torch.int64, contiguous=False)
+        if targets is not None:
+            ops._chk(targets, "targets", torch.int64, contiguous=False)
+        if not self.check_ids:
+            return
         V = self.token_embedding_table.weight.shape[0]
         ops.check_ids(idx, V, "idx")
         if targets is not None:
-            ops._chk(targets, "targets", torch.int64, contiguous=False)
             ops.check_ids(targets, V if not hasattr(self, "lm_head") else self.lm_head.weight.shape[0], "targets")
 
     def forward(self, idx, targets=None):

@@ -93,3 +93,49 @@ class AdamW(torch.optim.Optimizer):
                 scale = 1.0 / self.world_size
             ops.adamw_step(fl.flat, fl.g, fl.m, fl.v, fl.hyper, fl.t, grad_scale=scale, advance=True)
         return loss
+
+    # ---- checkpointing: the moments and the step count live in the flat buffers, not in torch's per-parameter `state`; export /
+    # import them in torch.optim.AdamW's own format (state[i] = {"step", "exp_avg", "exp_avg_sq"}) so that a resumed run keeps
+    # its bias correction and moments, and a state_dict written by torch.optim.AdamW loads here (ref: src/train.py:121)
+    def state_dict(self):
+        sd = super().state_dict()                   # param_groups with indices; `state` is empty (nothing lives there)
+        state, base = {}, 0
+        for gi, group in enumerate(self.param_groups):
+            fl = self._flat.get(gi)
+            if fl is not None:
+                idx = {id(p): base + j for j, p in enumerate(group["params"])}
+                t = float(fl.t[2].item())
+                by_id = {id(p): p for p in group["params"]}
+                for i, pid in enumerate(fl.key):
+                    p = by_id.get(pid)
+                    if p is None:
+                        continue
+                    state[idx[pid]] = {"step": torch.tensor(t), "exp_avg": fl.view(fl.m, i, p).detach().clone(),
+                                       "exp_avg_sq": fl.view(fl.v, i, p).detach().clone()}
+            base += len(group["params"])
+        sd["state"] = state
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        state = state_dict.get("state", {})
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        base = 0
+        for gi, group in enumerate(self.param_groups):
+            have = [(j, p) for j, p in enumerate(group["params"]) if (base + j) in state]
+            if have:
+                params = [p for _, p in have]
+                if any(not p.is_cuda for p in params):
+                    raise RuntimeError("drakegpt_amd.optim.AdamW updates GPU parameters only (no CPU path)")
+                self._flat.pop(gi, None)
+                fl = self._adopt(gi, params)
+                steps = set()
+                for i, (j, p) in enumerate(have):
+                    st = state[base + j]
+                    fl.view(fl.m, i, p).copy_(st["exp_avg"].to(p.device, torch.float32))
+                    fl.view(fl.v, i, p).copy_(st["exp_avg_sq"].to(p.device, torch.float32))
+                    steps.add(int(float(st["step"])))
+                if len(steps) != 1:
+                    raise ValueError("drakegpt_amd.optim.AdamW keeps ONE step count per parameter group; the state holds " + str(sorted(steps)))
+                fl.t.copy_(ops.new_rng_state(0, params[0].device, steps.pop()))
+            base += len(group["params"])

@@ -110,6 +110,7 @@ def engine_loop(engine, n_train: int, T: int, B: int, rank: int, world: int, ite
         engine.step()
         if (it + 1) % eval_interval == 0:
             on_eval(it)
+    engine.check_status()         # end of the run: a timed-out dW hand-over must not end in a saved checkpoint
 
 
 def main(argv=None):
@@ -187,6 +188,11 @@ def main(argv=None):
 
     def on_eval(it):
         model.eval()
+        if engine is not None:
+            # the evaluation synchronises the host for its losses anyway: the one place inside the loop where reading the
+            # grouped dW GEMM's sticky error word costs nothing.  Raises (-> non-zero exit) if a hand-over ever timed out:
+            # every weight gradient since then is suspect, and the losses would still look plausible.
+            engine.check_status()
         losses = evaluate_loss(train_dev, val_dev, model, args.eval_iters, T, B, device, engine=engine)
         sched["steps"] += 1
         lr = cyclic_lr(sched["steps"], base_lr, max_lr)

@@ -310,3 +310,54 @@ def test_train_harness_on_text_and_on_pt_files(dev, golden_dir, tmp_path, capsys
     # .pt files alone (no text): the vocabulary is taken from the streams
     train.main(common + ["--train-data", tp, "--val-data", vp, "--iters", "4"])
     assert '"val_loss"' in capsys.readouterr().out
+
+
+def test_dw_handover_error_word_stops_the_harness(dev):
+    """a timed-out split-K hand-over of the grouped dW GEMM sets a sticky error word and the launch carries
+    on with incomplete sums -- the losses still look plausible.  The harness reads the word wherever it synchronises anyway
+    (on_eval, end of the run; bench.py after its timed region) and raises.  Here the word is set by hand."""
+    import drakegpt_amd as D
+    from drakegpt_amd import train
+    from drakegpt_amd.engine import TrainEngine
+    torch.manual_seed(0)
+    B, T, C = 8, 64, 128
+    m = D.TransformerLM(V, C, T, 2, 2, 0.0, precision="bf16").to(dev).train()
+    eng = TrainEngine(m, B, T, lr=1e-3, seed=1, use_graph=False)
+    assert eng.grouped_dw
+    n_train = 4000
+    eng.set_corpus(torch.randint(0, V, (n_train,), generator=torch.Generator().manual_seed(1)))
+    seen = []
+    train.engine_loop(eng, n_train, T, B, 0, 1, 4, 2, lambda it: (eng.check_status(), seen.append(it)), dev, generator=torch.Generator().manual_seed(2))
+    assert seen == [1, 3] and eng.tn_workspaces
+    ws = next(iter(eng.tn_workspaces.values()))
+    ws[-16:].view(torch.int32)[0] = 1                 # what dg_gemm_tn_grouped's bounded wait leaves behind when it runs out
+    with pytest.raises(RuntimeError, match="hand-over timed out"):
+        eng.check_status()
+    with pytest.raises(RuntimeError, match="hand-over timed out"):      # the loop's own end-of-run check (no evaluation in range)
+        train.engine_loop(eng, n_train, T, B, 0, 1, 2, 100, lambda it: None, dev, generator=torch.Generator().manual_seed(3))
+    ws[-16:].view(torch.int32)[0] = 0
+    eng.check_status()
+
+
+def test_bench_entry_under_torch_distributed_run():
+    """the exact entry the driver's SCALE leg uses -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` --
+    with N = 1 (the box has one GPU): a fresh child, a world-size-1 "nccl" group created before any other GPU call, one JSON
+    line on stdout carrying the contract's fields"""
+    import json
+    import random
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(random.randint(20000, 40000)), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+           "--no-extra", "--no-cpu-baseline", "--no-kernel-timing"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["parallelism"] == "dp1" and "TransformerLM_scaled" in out["config"]["workload"] and out["dtype"] == "bf16"

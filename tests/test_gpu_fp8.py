@@ -499,3 +499,42 @@ def test_gpt2_medium_shape_fp8_engine_steps(dev):
     unseen[x.reshape(-1)] = False
     assert torch.all(gt[unseen] == 0) and torch.all(gt[~unseen].abs().sum(1) > 0)
     assert torch.all(g8["position_embedding_table.weight"].abs().sum(1) > 0)
+
+
+@pytest.mark.parametrize("fmt", [torch.float8_e4m3fn, torch.float8_e5m2])
+def test_fp8_casts_propagate_non_finite_values(dev, fmt):
+    """fmaxf drops a NaN from the recorded amax and the min / max clamp turns a NaN element into -FMAX, so a diverging
+    fp8 run trained on saturated values.  Now a NaN / Inf element poisons the recorded maximum (integer max on |x| bit patterns),
+    a poisoned maximum makes the scale NaN, and a NaN element stays NaN through the cast."""
+    from drakegpt_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(64, 256, generator=g).bfloat16().to(dev)
+    # just-in-time scaling: the NaN reaches amax, scale_inv and therefore every element
+    xn = x.clone()
+    xn[3, 17] = float("nan")
+    q, sinv = ops.fp8_quantize(xn, fmt)
+    assert torch.isnan(sinv).all() and torch.isnan(q.float()).all()
+    xi = x.clone()
+    xi[5, 1] = float("inf")
+    q, sinv = ops.fp8_quantize(xi, fmt)
+    assert torch.isnan(sinv).all()
+    # delayed scaling: step k casts with step k-1's (finite) maximum -- the NaN element itself stays NaN, the others are cast
+    # normally -- and records a NaN maximum; step k+1 then has a NaN scale
+    parts2 = torch.zeros(2 * ops.FP8_AMAX_PARTS, device=dev)
+    state = ops.new_rng_state(1, dev, 0)
+    ops.fp8_quantize(x, fmt, amax=parts2[:ops.FP8_AMAX_PARTS])
+    parts2[ops.FP8_AMAX_PARTS:].copy_(parts2[:ops.FP8_AMAX_PARTS])
+    q0, s0 = ops.fp8_quantize_delayed(x, fmt, parts2, state)
+    assert torch.isfinite(s0).all() and torch.isfinite(q0.float()).all()
+    ops.state_advance(state)
+    q1, s1 = ops.fp8_quantize_delayed(xn, fmt, parts2, state)
+    f1 = q1.float()
+    assert torch.isfinite(s1).all() and torch.isnan(f1[3, 17]) and int(torch.isnan(f1).sum()) == 1
+    ops.state_advance(state)
+    q2, s2 = ops.fp8_quantize_delayed(x, fmt, parts2, state)
+    assert torch.isnan(s2).all() and torch.isnan(q2.float()).all()
+    # ... and the GEMM carries it into its output (what turns the loss NaN)
+    w = torch.randn(128, 256, generator=g).bfloat16().to(dev)
+    wq, ws = ops.fp8_quantize(w, torch.float8_e4m3fn)
+    out = ops.gemm_nt(q1, wq, torch.bfloat16, scale_a=s1, scale_b=ws)
+    assert torch.isnan(out[3].float()).all() and torch.isfinite(out[4].float()).all()

@@ -191,6 +191,9 @@ def test_staged_offsets_equal_the_reference_draw_order(iters, interval, world):
             self.seen.append(self.block[self.at])
             self.at += 1
 
+        def check_status(self):                      # engine_loop's end-of-run check of the dW hand-over error word
+            self.checked = True
+
     def eval_draws(gen, sink):
         for _ in range(2 * eval_iters):                               # train, then val: evaluate_loss's draws
             sink.append(preprocessing.draw_offsets(n_train, T, B, gen))
@@ -207,7 +210,7 @@ def test_staged_offsets_equal_the_reference_draw_order(iters, interval, world):
             want.append(ix[rank * B:(rank + 1) * B])
             if (it + 1) % interval == 0:
                 eval_draws(gen2, ev2)
-        assert len(eng.seen) == iters and all(torch.equal(a, b) for a, b in zip(eng.seen, want))
+        assert len(eng.seen) == iters and all(torch.equal(a, b) for a, b in zip(eng.seen, want)) and eng.checked
         assert len(ev) == len(ev2) and all(torch.equal(a, b) for a, b in zip(ev, ev2))
         assert torch.equal(torch.randint(100, (4,), generator=gen), torch.randint(100, (4,), generator=gen2))
 
