@@ -18,7 +18,7 @@ DG_F32 = 0
 DG_BF16 = 1
 DG_FP8_E4M3 = 2
 DG_FP8_E5M2 = 3
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class GemmNtArgs(C.Structure):
@@ -49,6 +49,21 @@ class GemmNtArgs(C.Structure):
         ("fp8_out_parts2", C.c_void_p),
         ("fp8_out_step", C.c_void_p),
         ("fp8_out_scale_inv", C.c_void_p),
+    ]
+
+
+class BlockChainArgs(C.Structure):
+    """struct dg_block_chain_args"""
+    _fields_ = [
+        ("mode", C.c_int32), ("M", C.c_int32), ("C", C.c_int32), ("eps", C.c_float),
+        ("o", C.c_void_p), ("x", C.c_void_p),
+        ("wproj", C.c_void_p), ("bproj", C.c_void_p), ("x1", C.c_void_p),
+        ("ln2w", C.c_void_p), ("ln2b", C.c_void_p), ("mean2", C.c_void_p), ("rstd2", C.c_void_p), ("h2", C.c_void_p),
+        ("w1", C.c_void_p), ("b1", C.c_void_p), ("f", C.c_void_p), ("sign_bits", C.c_void_p), ("sign_bits_bytes", C.c_int64),
+        ("w2", C.c_void_p), ("b2", C.c_void_p), ("x2", C.c_void_p), ("x2_bf16", C.c_void_p),
+        ("ln1w", C.c_void_p), ("ln1b", C.c_void_p), ("mean1", C.c_void_p), ("rstd1", C.c_void_p), ("h1", C.c_void_p),
+        ("wqkv", C.c_void_p), ("qkv", C.c_void_p),
+        ("dropout_p", C.c_float), ("rng_state", C.c_void_p), ("site_proj", C.c_uint32), ("site_ffn", C.c_uint32),
     ]
 
 
@@ -103,6 +118,10 @@ SIGNATURES = {
     "dg_reduce_sum": [_vp, _i64, _f, _vp, _vp],
     "dg_softmax_rows": [_vp, _i64, _vp, _i64, _i, _i, _vp],
     "dg_adamw_step": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f, _vp, _i, _vp],
+    "dg_block_chain_supported": [_i, _i],
+    "dg_block_chain_fwd": [C.POINTER(BlockChainArgs), _vp],
+    "dg_pack_chain_weights": [_vp, _i64, _vp, _i, _i, _vp],
+    "dg_pack_chain_weights_batched": [_vp, _i, _i, _vp],
 }
 
 

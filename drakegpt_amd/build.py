@@ -33,6 +33,7 @@ SOURCES = [
     "attention_simple.hip",
     "attention_mfma.hip",
     "cross_entropy.hip",
+    "chain.hip",
 ]
 
 

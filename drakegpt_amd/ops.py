@@ -601,3 +601,98 @@ def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor, rng_st
     n = p.numel() if n is None else n
     check(lib.dg_adamw_step(_p(p), _p(g), _p(m), _p(v), n, _p(hyper), _p(rng_state), float(grad_scale), _p(shadow_bf16), int(advance),
                             _stream()), "dg_adamw_step")
+
+
+def block_chain_supported(M: int, C: int, dtype: torch.dtype) -> bool:
+    """can dg_block_chain_fwd run this shape?  (bf16 operands, C = 384, M % 64 == 0)"""
+    return dtype == torch.bfloat16 and bool(lib.dg_block_chain_supported(int(M), int(C)))
+
+
+def pack_chain_weights(W: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """W [N, K] bf16 (N % 384 == 0, K % 32 == 0) -> the packed operand dg_block_chain_fwd streams (same shape / byte count)"""
+    _chk(W, "W", torch.bfloat16, contiguous=False)
+    N, K = W.shape
+    if out is None:
+        out = torch.empty((N, K), dtype=torch.bfloat16, device=W.device)
+    _chk(out, "out", torch.bfloat16)
+    check(lib.dg_pack_chain_weights(_p(W), _ld(W), _p(out), N, K, _stream()), "dg_pack_chain_weights")
+    return out
+
+
+def make_pack_table(pairs, device) -> tuple:
+    """descriptor table for pack_chain_weights_batched: pairs = [(W [N, K] bf16, packed [N, K] bf16)]"""
+    rows, first = [], 0
+    for W, Pk in pairs:
+        N, K = W.shape
+        if N % 384 or K % 32:
+            raise RuntimeError("pack_chain_weights: N % 384 == 0 and K % 32 == 0 required")
+        rows.append([W.data_ptr(), Pk.data_ptr(), N, K, first, _ld(W)])
+        first += (N // 384) * (K // 32)
+    return torch.tensor(rows, dtype=torch.int64, device=device), len(rows), first
+
+
+def pack_chain_weights_batched(table: Tensor, n_desc: int, total_stages: int) -> None:
+    _chk(table, "table", torch.int64)
+    check(lib.dg_pack_chain_weights_batched(_p(table), n_desc, total_stages, _stream()), "dg_pack_chain_weights_batched")
+
+
+def block_chain_fwd(mode: int, M: int, Cd: int, *, o: Optional[Tensor] = None, x: Optional[Tensor] = None, wproj=None, bproj=None, ln2w=None, ln2b=None,
+                    w1=None, b1=None, w2=None, b2=None, ln1w=None, ln1b=None, wqkv=None, f: Optional[Tensor] = None, x1: Optional[Tensor] = None,
+                    dropout_p: float = 0.0, rng_state: Optional[Tensor] = None, site_proj: int = 0, site_ffn: int = 0, eps: float = 1e-5) -> dict:
+    """row-local pieces of a residual block with the LayerNorm inside the producing GEMM's epilogue (dg_block_chain_fwd).
+    mode 0: proj .. the next block's QKV in one launch; 1: last block (x2 comes back as bf16); 2: head (LayerNorm 1 + QKV of the
+    first block on x); 3: proj + residual + LayerNorm 2 (o, x -> x1, h2, mean2, rstd2); 4: FFN2 + residual + the next block's
+    LayerNorm 1 (f, x1 -> x2, h1, mean1, rstd1).  Weights are the PACKED bf16 operands (pack_chain_weights of the [out, in]
+    matrices).  Returns the tensors the separate launches would have produced, by name."""
+    from ._lib import BlockChainArgs
+    dev = next(t for t in (x, o, f) if t is not None).device
+    a = BlockChainArgs()
+    a.mode, a.M, a.C, a.eps = mode, M, Cd, eps
+    out = {}
+    has_proj, has_ffn1, has_ffn2 = mode in (0, 1, 3), mode in (0, 1), mode in (0, 1, 4)
+    has_qkv, ln1 = mode in (0, 2), mode in (0, 2, 4)
+
+    def new(name, shape, dtype):
+        t = out[name] = torch.empty(shape, dtype=dtype, device=dev)
+        return t.data_ptr()
+
+    def inp(t, name, dtype, n=None):
+        _chk(t, name, dtype)
+        if n is not None and t.numel() != n:
+            raise RuntimeError(f"block_chain_fwd: {name} must hold {n} values, got {t.numel()}")
+        return t.data_ptr()
+    bf, f32 = torch.bfloat16, torch.float32
+    if mode != 4:
+        a.x = inp(x, "x", f32, M * Cd)
+    if has_proj:
+        a.o = inp(o, "o", bf, M * Cd)
+        a.wproj, a.bproj = inp(wproj, "wproj", bf, Cd * Cd), inp(bproj, "bproj", f32, Cd)
+        a.ln2w, a.ln2b = inp(ln2w, "ln2w", f32, Cd), inp(ln2b, "ln2b", f32, Cd)
+        a.x1 = new("x1", (M, Cd), f32)
+        a.mean2, a.rstd2 = new("mean2", (M,), f32), new("rstd2", (M,), f32)
+        a.h2 = new("h2", (M, Cd), bf)
+    if has_ffn1:
+        a.w1, a.b1 = inp(w1, "w1", bf, 4 * Cd * Cd), inp(b1, "b1", f32, 4 * Cd)
+        a.f = new("f", (M, 4 * Cd), bf)
+        bits = out["bits"] = new_sign_bits(M, 4 * Cd, dev)
+        a.sign_bits, a.sign_bits_bytes = bits.data_ptr(), bits.numel()
+    if has_ffn2:
+        if mode == 4:
+            a.f, a.x1 = inp(f, "f", bf, M * 4 * Cd), inp(x1, "x1", f32, M * Cd)
+        a.w2, a.b2 = inp(w2, "w2", bf, 4 * Cd * Cd), inp(b2, "b2", f32, Cd)
+        if mode == 1:
+            a.x2_bf16 = new("x2", (M, Cd), bf)
+        else:
+            a.x2 = new("x2", (M, Cd), f32)
+    if ln1:
+        a.ln1w, a.ln1b = inp(ln1w, "ln1w", f32, Cd), inp(ln1b, "ln1b", f32, Cd)
+        a.mean1, a.rstd1 = new("mean1", (M,), f32), new("rstd1", (M,), f32)
+        a.h1 = new("h1", (M, Cd), bf)
+    if has_qkv:
+        a.wqkv = inp(wqkv, "wqkv", bf, 3 * Cd * Cd)
+        a.qkv = new("qkv", (M, 3 * Cd), bf)
+    a.dropout_p = float(dropout_p)
+    a.rng_state = _p(rng_state) if dropout_p > 0.0 else None
+    a.site_proj, a.site_ffn = site_proj, site_ffn
+    check(lib.dg_block_chain_fwd(C.byref(a), _stream()), "dg_block_chain_fwd")
+    return out

@@ -45,7 +45,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 12   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 13   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -342,6 +342,42 @@ int dg_softmax_rows(const float* logits, int64_t ldl, float* probs, int64_t ldp,
  * rng_state is its arrival counter: zero before and after every launch). */
 int dg_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
                   uint32_t* rng_state, float grad_scale, void* shadow_bf16, int advance_step, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The row-local chain of one residual block in ONE launch (bf16 operands, C = 384, M % 64 == 0) -- ref:
+ * src/model_component.py:454 (proj) + :505 (x + ...), :506 + :488-489 (LayerNorm 2), :320-325 (FeedForward3), the second
+ * residual add, and the NEXT block's :505 LayerNorm 1 + :392-393,404 (its 3 * NH per-head Linears as one packed operand):
+ *     x1 = x + dropout(o wproj^T + bproj; site_proj)      h2 = LN(x1; ln2w, ln2b)      f = relu(h2 w1^T + b1)
+ *     x2 = x1 + dropout(f w2^T + b2; site_ffn)            h1 = LN(x2; ln1w, ln1b)      qkv = h1 wqkv^T
+ * It replaces four dg_gemm_nt launches and two dg_layernorm_fwd launches per block and writes exactly what they wrote (the
+ * tensors the backward pass reads): x1, mean2 / rstd2, h2, f, the ReLU sign bits in dg_gemm_nt's opaque layout for an
+ * [M, 4C] output (dg_gemm_nt_sign_bits_bytes(M, 4 * C) bytes), x2, mean1 / rstd1, h1, qkv.  Dropout masks are those of
+ * dg_gemm_nt's epilogue (same site keys and element indices).  A workgroup owns 64 rows and walks the whole chain for them.
+ * The four weight operands (wproj [C, C], w1 [4C, C], w2 [C, 4C], wqkv [3C, C]; bf16, [out, in]) are passed PACKED: in the
+ * order the kernel streams them, as written by dg_pack_chain_weights (same byte count as the matrix; refresh after every
+ * optimizer step, like the W^T operands of the dX GEMMs).
+ * mode 0: everything above.  mode 1 (last block): stops behind the second residual add and writes x2 as bf16 (x2_bf16, the
+ * operand of lm_head; x2 / ln1* / h1 / wqkv / qkv unused).  mode 2 (head: the first block's LayerNorm 1 on the embedding
+ * output): h1 = LN(x), qkv = h1 wqkv^T only. */
+typedef struct dg_block_chain_args {
+    int32_t mode, M, C;
+    float eps;
+    const void* o; const float* x;
+    const void* wproj; const float* bproj; float* x1;
+    const float* ln2w; const float* ln2b; float* mean2; float* rstd2; void* h2;
+    const void* w1; const float* b1; void* f; uint8_t* sign_bits; int64_t sign_bits_bytes;
+    const void* w2; const float* b2; float* x2; void* x2_bf16;
+    const float* ln1w; const float* ln1b; float* mean1; float* rstd1; void* h1;
+    const void* wqkv; void* qkv;
+    float dropout_p; const uint32_t* rng_state; uint32_t site_proj, site_ffn;
+} dg_block_chain_args;
+int dg_block_chain_supported(int M, int C);
+int dg_block_chain_fwd(const dg_block_chain_args* args, void* stream);
+/* w [N, K] bf16 row-major with leading dimension ld (N % 384 == 0, K % 32 == 0) -> packed (N * K elements).  Batched form: a
+ * device table of n_desc rows {src, dst, N, K, first stage of the matrix (prefix sum of N / 384 * K / 32), ld} (int64 each):
+ * every weight matrix of a model in one launch of total_stages workgroups. */
+int dg_pack_chain_weights(const void* w, int64_t ld, void* packed, int N, int K, void* stream);
+int dg_pack_chain_weights_batched(const int64_t* desc, int n_desc, int total_stages, void* stream);
 
 #ifdef __cplusplus
 }
