@@ -74,7 +74,9 @@ __device__ __forceinline__ void ch_wait_vm(int n) {          // counted wait on 
         case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
         case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
         case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -100,7 +102,14 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
         for (int i = 0; i < grp * p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
     }
 
-    auto n_of = [&](int s) -> int { return (HAS_FFN2 && s >= O_FFN2 && s < Q0) ? 7 : 6; };     // DMA pieces per loader wave
+    // DMA pieces per loader wave and stage.  FFN2 inside a longer chain: 6 + 1 (K = 32 of the hidden block in the ring's activation
+    // part).  MODE 4 (FFN2 alone): the resident-A region is free, so the hidden block streams through IT as six slots of whole
+    // 128-byte-row K = 64 tiles (full cache lines from memory that is cold inside the step; half lines cost 46 instead of 33 us):
+    // even stages carry 2 more pieces, odd stages none.
+    auto n_of = [&](int s) -> int {
+        if (MODE == 4) return (s & 1) ? 6 : 8;
+        return (HAS_FFN2 && s >= O_FFN2 && s < Q0) ? 7 : 6;
+    };
     // does a LayerNorm epilogue follow stage s (the last K step of proj / FFN2)?
     auto ln_after = [&](int s) -> bool { return (HAS_PROJ && s == O_FFN1 - 1) || (LN_FFN2 && s == Q0 - 1); };
 
@@ -130,7 +139,17 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
                     __builtin_amdgcn_global_load_lds((gptr_t)(src + voff + i * 1024), (lptr_t)(buf + lw * 6144 + i * 1024), 16, 0, 0);
-                if (HAS_FFN2 && s >= O_FFN2 && s < Q0)
+                if (MODE == 4) {
+                    if (!(s & 1)) {                                       // K = 64 tile u = s / 2 of the hidden block -> slot u % 6 (standard image)
+                        const int u = s >> 1;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int pr = lw * 2 + j;
+                            const char* src = fblk + (int64_t)(pr * 8 + prow) * (4 * C * 2) + u * 128 + ((slot ^ prow) << 4);
+                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + CH_ARES + (u % 6) * 8192 + pr * 1024), 16, 0, 0);
+                        }
+                    }
+                } else if (HAS_FFN2 && s >= O_FFN2 && s < Q0)
                     __builtin_amdgcn_global_load_lds((gptr_t)(fblk + (s - O_FFN2) * 64 + aoff), (lptr_t)(buf + CH_STAGE_B + lw * 1024), 16, 0, 0);
             };
             if (HAS_PROJ) {
@@ -145,7 +164,7 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
             }
             for (int s = 0; s < CH_NST; ++s) issue(s);
             if (MODE == 2) __builtin_amdgcn_s_barrier();                  // E of the head's LayerNorm (the MFMA waves' prologue)
-            ch_wait_vm(18);                                               // stages 1..3 (6 pieces each) may fly; resident A + stage 0 landed
+            ch_wait_vm(n_of(1) + n_of(2) + n_of(3));                      // stages 1..3 may fly; resident A + stage 0 landed
             __builtin_amdgcn_s_barrier();                                 // P
             if (p.dbg == 5) {                                             // ablation: the loaders do nothing but keep the barrier sequence
                 for (int b = 0; b + 1 < S; ++b) {
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
         for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(buf + i * 2048);
     };
     auto read_A_res = [&](u32x4 (&fa)[2], int t) {
-        const char* buf = lds + (t >> 1) * 8192 + ((t & 1) ? a_off1 : a_off0);
+        const char* buf = lds + ((t >> 1) % 6) * 8192 + ((t & 1) ? a_off1 : a_off0);      // (MODE 4: six slots walked round and round)
 #pragma unroll
         for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)(buf + i * 2048);
     };
@@ -364,7 +383,7 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
         }
         __builtin_amdgcn_s_barrier();                                     // P
         read_B(fb0, 0);
-        if (MODE == 4) read_A_ring(fa0, 0); else read_A_res(fa0, 0);
+        read_A_res(fa0, 0);
         // one GEMM piece = NSTEP K steps entering with (fa0, fb0) loaded for its first step; `ring_a`: A operand from the ring.
         // After the piece's last MFMA the caller runs the epilogue; `next`: 0 = nothing follows in this block, 1 = prefetch B and A
         // of the following piece's first step, 2 = B only (its A operand is written by this piece's epilogue: read it behind the
@@ -461,7 +480,7 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
         }
         if (HAS_FFN2) {
             // ---- FFN2 + residual (+ LayerNorm 1 of the next block)
-            piece(4 * KS, true, HAS_QKV ? 2 : 0, false, false, true);
+            piece(4 * KS, MODE != 4, HAS_QKV ? 2 : 0, false, false, true);
             if (p.dbg == 4 || p.dbg == 5) { if (LN_FFN2) __builtin_amdgcn_s_barrier(); }
             else {
                 float xv[2][3][8];

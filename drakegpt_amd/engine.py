@@ -63,6 +63,7 @@ class ShadowWeights:
         self.bwd_map: Dict[int, Tensor] = {}
         self.fwd8_map: Dict[int, Tuple[Tensor, Tensor]] = {}      # fp8 mode: (e4m3 copy, dequantisation scale [1])
         self.bwd8_map: Dict[int, Tuple[Tensor, Tensor]] = {}
+        self.pack_map: Dict[int, Tensor] = {}                      # proj / second FFN Linear in dg_block_chain_fwd's streaming order
 
     def fwd(self, W: Tensor) -> Tensor:
         return self.fwd_map[W.data_ptr()]
@@ -72,6 +73,9 @@ class ShadowWeights:
 
     def fwd8(self, W: Tensor):
         return self.fwd8_map[W.data_ptr()]
+
+    def pack(self, W: Tensor) -> Optional[Tensor]:
+        return self.pack_map.get(W.data_ptr())
 
     def bwd8(self, W: Tensor):
         return self.bwd8_map[W.data_ptr()]
@@ -202,6 +206,12 @@ class TrainEngine:
         # bf16: every dW of the step comes from ONE grouped GEMM at the end of backward, written straight into the
         # flat gradient (no split-K slabs); fp32 parity mode keeps the per-matrix split-K path
         self.grouped_dw = self.act == torch.bfloat16 and self.M % 64 == 0
+        # LayerNorm inside the epilogue of the GEMM that produces its input (dg_block_chain_fwd modes 3 / 4: proj + residual + LN2,
+        # FFN2 + residual + the next block's LN1): bf16 mode at the width the kernel is built for.  OFF by default (DG_CHAIN_LN=1 turns
+        # it on): measured inside the captured step (round 3, same box) proj + LN2 24.7 us against 17.4 + 8.8, FFN2 + LN1' 44.2 us
+        # against 33.5 + 8.8, plus 7.8 us for the packed-weight refresh: 2.558 vs 2.528 ms per step
+        self.chain_ln = (_os.environ.get("DG_CHAIN_LN", "0") == "1" and not self.fp8 and self.NH * self.H == self.C
+                         and ops.block_chain_supported(self.M, self.C, self.act))
         self._build_layout()
         self.dp_buckets = self._choose_buckets(self._dp_buckets_arg)
         self._alloc_and_adopt()
@@ -406,9 +416,15 @@ class TrainEngine:
             n_fp8 = sum(1 for key in self.layA.entries if key != "lm.w")
             self.wscale_f = torch.ones(n_fp8, dtype=torch.float32, device=dev)
             self.wscale_b = torch.ones(n_fp8, dtype=torch.float32, device=dev)
+        self.wpack_flat = torch.zeros(self.layA.size, dtype=torch.bfloat16, device=dev) if self.chain_ln else None
+        self._pack_pairs = []
         for key, (off, shape) in self.layA.entries.items():
             W = self.param_view(key)
             n = shape[0] * shape[1]
+            if self.chain_ln and (key.endswith(".wproj") or key.endswith(".w2")):
+                pk = self.wpack_flat[off:off + n].view(shape)
+                self.weights.pack_map[W.data_ptr()] = pk
+                self._pack_pairs.append((self.shadow[self.offA + off:self.offA + off + n].view(shape), pk))
             if self.shadow is not None:
                 self.weights.fwd_map[W.data_ptr()] = self.shadow[self.offA + off:self.offA + off + n].view(shape)
             else:
@@ -443,6 +459,10 @@ class TrainEngine:
             pairs = [(self.weights.fwd(W) if from_shadow else W, Wt) for W, Wt in self._mats]
             self._tr_table = ops.make_transpose_table(pairs, self.dev)
         ops.transpose_cast_batched(*self._tr_table, self.act, in_dtype=torch.bfloat16 if from_shadow else torch.float32)
+        if self._pack_pairs:
+            if getattr(self, "_pack_table", None) is None:
+                self._pack_table = ops.make_pack_table(self._pack_pairs, self.dev)
+            ops.pack_chain_weights_batched(*self._pack_table)
         if self.fp8:
             # e4m3 copies of every block matrix and of every W^T, per-matrix scales: two launch pairs for the whole model
             n = self.seg_f.shape[0]
@@ -470,11 +490,20 @@ class TrainEngine:
         else:
             h = ops.embed_fwd(x_idx, self.param_view("tok"), self.param_view("pos"), onehot=onehot).view(M, self.C)
         saved = []
+        pre = None          # LayerNorm output for the next sub-layer, when the GEMM in front of it produced it (chain_ln)
         for l in range(self.L):
             P = self._layer_params(l)
-            h, sa = S.attn_fwd(run, h, P["ln1w"], P["ln1b"], P["wqkv"], P["wproj"], P["bproj"], True, B, T, self.NH, self.H, p, p, l)
+            nxt = [] if self.chain_ln else None
+            h, sa = S.attn_fwd(run, h, P["ln1w"], P["ln1b"], P["wqkv"], P["wproj"], P["bproj"], True, B, T, self.NH, self.H, p, p, l,
+                               pre=pre, fuse_ln=(P["ln2w"], P["ln2b"]) if self.chain_ln else None, nxt=nxt)
+            pre = nxt[0] if nxt else None
+            last = l == self.L - 1
+            nxt = [] if (self.chain_ln and not last) else None
+            Pn = self._layer_params(l + 1) if nxt is not None else None
             h, sf = S.ffn_fwd(run, h, P["ln2w"], P["ln2b"], P["w1"], P["b1"], P["w2"], P["b2"], True, p, l,
-                              out_dtype=self.act if (l == self.L - 1 and self.last_block_act) else torch.float32)
+                              out_dtype=self.act if (last and self.last_block_act) else torch.float32,
+                              pre=pre, fuse_ln=(Pn["ln1w"], Pn["ln1b"]) if nxt is not None else None, nxt=nxt)
+            pre = nxt[0] if nxt else None
             if want_grad:
                 saved.append((sa, sf))
         if self.bf16_logits and y_idx is not None and not self.keep_logits:

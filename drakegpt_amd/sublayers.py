@@ -276,19 +276,38 @@ def _ln_tail(run: Run, dh: Tensor, x2d: Tensor, ln_w: Tensor, mean, rstd, dresid
 
 # ------------------------------------------------------------------------------------------------
 # attention sub-layer
+def _chain_ok(run: Run, x2d: Tensor, W: Optional[Tensor]) -> bool:
+    """can the producing GEMM also run the LayerNorm that follows it (dg_block_chain_fwd modes 3 / 4)?"""
+    pack = getattr(run.weights, "pack", None)
+    return (W is not None and pack is not None and not run.fp8 and x2d.dtype == torch.float32
+            and ops.block_chain_supported(x2d.shape[0], x2d.shape[1], run.act) and pack(W) is not None)
+
+
 def attn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor], wqkv: Tensor,
              wproj: Optional[Tensor], bproj: Optional[Tensor], residual: bool,
-             B: int, T: int, NH: int, H: int, p_attn: float, p_proj: float, layer: int):
-    """x2d [B*T, C].  Returns y [B*T, C_out] fp32 and the tensors backward needs."""
-    if ln_w is not None:
+             B: int, T: int, NH: int, H: int, p_attn: float, p_proj: float, layer: int,
+             pre=None, fuse_ln=None, nxt: Optional[list] = None):
+    """x2d [B*T, C].  Returns y [B*T, C_out] fp32 and the tensors backward needs.
+    pre = (h, mean, rstd): the LayerNorm of x2d, already computed by the GEMM that produced x2d.  fuse_ln = (gamma, beta) of the
+    LayerNorm that FOLLOWS this sub-layer: when the row-complete form is available the projection's epilogue also runs it and
+    (h_next, mean, rstd) is appended to `nxt` (else nothing is appended and the caller runs the LayerNorm itself)."""
+    if pre is not None:
+        h, mean, rstd = pre
+    elif ln_w is not None:
         h, mean, rstd = ops.layernorm_fwd(x2d, ln_w, ln_b, run.act)
     else:
         h, mean, rstd = _as_act(run, x2d), None, None
     qkv = linear_nt(run, h, wqkv, run.act, fp8_site=f"{layer}.h1")
     o, lse = ops.attn_fwd(qkv, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer))
     if wproj is not None:
-        y = linear_nt(run, o, wproj, torch.float32, fp8_site=f"{layer}.o", bias=bproj, dropout_p=run.p(p_proj),
-                      rng_state=run.rng, site=site_proj(layer), residual=x2d if residual else None)
+        if fuse_ln is not None and nxt is not None and residual and o.shape[1] == x2d.shape[1] and _chain_ok(run, x2d, wproj):
+            r = ops.block_chain_fwd(3, x2d.shape[0], x2d.shape[1], o=o, x=x2d, wproj=run.weights.pack(wproj), bproj=bproj, ln2w=fuse_ln[0],
+                                    ln2b=fuse_ln[1], dropout_p=run.p(p_proj), rng_state=run.rng, site_proj=site_proj(layer))
+            y = r["x1"]
+            nxt.append((r["h2"], r["mean2"], r["rstd2"]))
+        else:
+            y = linear_nt(run, o, wproj, torch.float32, fp8_site=f"{layer}.o", bias=bproj, dropout_p=run.p(p_proj),
+                          rng_state=run.rng, site=site_proj(layer), residual=x2d if residual else None)
     else:
         if residual:
             raise RuntimeError("residual attention without a projection is not a reference configuration")
@@ -330,10 +349,13 @@ def attn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], wqkv: Tensor, 
 # feed-forward sub-layer
 def ffn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor], w1: Tensor, b1: Tensor,
             w2: Optional[Tensor], b2: Optional[Tensor], residual: bool, p: float, layer: int,
-            out_dtype: torch.dtype = torch.float32):
+            out_dtype: torch.dtype = torch.float32, pre=None, fuse_ln=None, nxt: Optional[list] = None):
     """out_dtype: the engine asks for the activation type from the LAST block -- its output only feeds lm_head, which would
-    cast it anyway (same rounding), so the fp32 copy and the cast launch disappear."""
-    if ln_w is not None:
+    cast it anyway (same rounding), so the fp32 copy and the cast launch disappear.  pre / fuse_ln / nxt: see attn_fwd (here
+    the LayerNorm that follows is the NEXT block's first one, run by the second Linear's epilogue)."""
+    if pre is not None:
+        h, mean, rstd = pre
+    elif ln_w is not None:
         h, mean, rstd = ops.layernorm_fwd(x2d, ln_w, ln_b, run.act)
     else:
         h, mean, rstd = _as_act(run, x2d), None, None
@@ -348,8 +370,15 @@ def ffn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor
         bits = ops.new_sign_bits(h.shape[0], w1.shape[0], h.device)
     f8 = _fused_fp8_out(run, f"{layer}.f", h.shape[0], w1.shape[0], w1.shape[1], h.device) if bits is not None else None
     f = linear_nt(run, h, w1, run.act, fp8_site=f"{layer}.h2", bias=b1, relu=True, sign_bits_out=bits, fp8_out=f8)
-    y = linear_nt(run, f, w2, out_dtype, fp8_site=f"{layer}.f", x8=(f8[0], f8[3]) if f8 is not None else None, bias=b2,
-                  dropout_p=run.p(p), rng_state=run.rng, site=site_ffn(layer), residual=x2d if residual else None)
+    if (fuse_ln is not None and nxt is not None and residual and out_dtype == torch.float32 and w1.shape[0] == 4 * x2d.shape[1]
+            and _chain_ok(run, x2d, w2)):
+        r = ops.block_chain_fwd(4, x2d.shape[0], x2d.shape[1], f=f, x1=x2d, w2=run.weights.pack(w2), b2=b2, ln1w=fuse_ln[0], ln1b=fuse_ln[1],
+                                dropout_p=run.p(p), rng_state=run.rng, site_ffn=site_ffn(layer))
+        y = r["x2"]
+        nxt.append((r["h1"], r["mean1"], r["rstd1"]))
+    else:
+        y = linear_nt(run, f, w2, out_dtype, fp8_site=f"{layer}.f", x8=(f8[0], f8[3]) if f8 is not None else None, bias=b2,
+                      dropout_p=run.p(p), rng_state=run.rng, site=site_ffn(layer), residual=x2d if residual else None)
     return y, (x2d, h, mean, rstd, f, bits)
 
 
