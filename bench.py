@@ -304,8 +304,9 @@ def kernel_roofline(eng, offsets, peak_tflops):
     def tng(problems, workspace=None):
         problems = list(problems)
         real_tng(problems, workspace)
-        fl = sum(2.0 * A.shape[0] * P * Q for A, _, _, P, Q in problems)
-        sym = "gemm_tn_grouped_kernel" if os.environ.get("DG_TN_TILE") == "128" else f"gemm_tn_grouped256_kernel<{1 if os.environ.get('DG_TN_WAVETILE') == '1' else 0}>"
+        fl = sum(2.0 * pr[0].shape[0] * pr[3] * pr[4] for pr in problems)
+        f8 = "true" if len(problems[0]) == 7 else "false"           # fp8 operands (precision fp8): (A, B, out, P, Q, scale_a, scale_b)
+        sym = "gemm_tn_grouped_kernel" if os.environ.get("DG_TN_TILE") == "128" else f"gemm_tn_grouped256_kernel<{1 if os.environ.get('DG_TN_WAVETILE') == '1' else 0},{f8}>"
         calls.append((sym, fl, lambda: real_tng(problems, workspace)))
 
     # HBM-bound kernels: algorithmic bytes per launch (what the kernel must read + write once; SURVEY 8d conventions)

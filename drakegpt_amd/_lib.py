@@ -18,7 +18,7 @@ DG_F32 = 0
 DG_BF16 = 1
 DG_FP8_E4M3 = 2
 DG_FP8_E5M2 = 3
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class GemmNtArgs(C.Structure):
@@ -74,6 +74,7 @@ class TnProblem(C.Structure):
         ("B", C.c_void_p), ("ldb", C.c_int64),
         ("out", C.c_void_p), ("ldo", C.c_int64),
         ("R", C.c_int32), ("P", C.c_int32), ("Q", C.c_int32), ("reserved", C.c_int32),
+        ("scale_a", C.c_void_p), ("scale_b", C.c_void_p),
     ]
 
 

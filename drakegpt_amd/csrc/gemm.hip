@@ -640,6 +640,18 @@ struct TnProblem {
 };
 // ws (256-row-tile kernel only): split-K workspace, [total_tiles][8 waves][16 KB] fp32 partials then [total_tiles][8] flags
 struct TnGroup { int n, total_tiles; int splits, tiles_pad; char* ws; unsigned* err; TnProblem pr[TN_MAX_GROUP]; };
+// fp8 operands (round 3): e5m2 dY x e4m3 X with one dequantisation factor per operand (device scalars).  Two more pointers per
+// problem: 48 problems per launch keep the kernel arguments under 4 KB (GPT-2-medium's 96 block matrices: two launches).
+#define TN_MAX_GROUP8 48
+struct TnProblem8 {
+    const char* A; const char* B; float* out;
+    const float* sa; const float* sb;         // dW = sa[0] * sb[0] * sum_r qA qB
+    int lda_b, ldb_b, ldo;
+    int P, Q, R, tiles_q, tile_begin;
+};
+struct TnGroup8 { int n, total_tiles; int splits, tiles_pad; char* ws; unsigned* err; TnProblem8 pr[TN_MAX_GROUP8]; };
+template <bool F8> struct TnGroupOf { typedef TnGroup type; };
+template <> struct TnGroupOf<true> { typedef TnGroup8 type; };
 
 __global__ __launch_bounds__(768) void gemm_tn_grouped_kernel(TnGroup gp) {
     __shared__ __attribute__((aligned(16))) char lds[GL_NST * GL_STAGE];
@@ -806,8 +818,17 @@ __global__ __launch_bounds__(768) void gemm_tn_grouped_kernel(TnGroup gp) {
 // addresses of the WT 1 branch so that the loop has no scratch traffic -- 466 us against 445 us with the reads and MFMAs held
 // in that order by sched_barriers, 594 us with the order left to the compiler.  The straight loop below already overlaps:
 // the two MFMA waves of a SIMD drift apart by themselves and one's reads run under the other's MFMAs.
-template <int WT>
-__global__ __launch_bounds__(WT ? 512 : 768) void gemm_tn_grouped256_kernel(TnGroup gp) {
+// F8 (round 3, WT 0 only): OCP fp8 operands -- A = dY as e5m2, B = X as e4m3, the copies the fp8 forward / dX GEMMs already made of
+// them.  A stage is 128 rows of the contraction instead of 64 at the same 48 KB (three [128 r][128 B] images), read with
+// ds_read_b64_tr_b8 (per 16-lane group an 8-row x 16-byte-column block, lane i receiving column i's eight rows; lane 2 r + h
+// supplies row r, bytes 8 h .. 8 h + 7 -- probed with tools/tr8_probe.hip) and multiplied with ONE v_mfma_f32_16x16x128_f8f6f4
+// per 16 x 16 block: per 128 rows the same 32 transposed reads per wave as the bf16 form needs for 64, half the operand bytes from
+// HBM, 16 MFMAs instead of 32.  Swizzle of the image: physical 16-byte chunk = chunk ^ (((row >> 1) & 3) | (((row >> 5) & 1) << 2))
+// -- rows two apart share their banks (128-byte rows, 64 banks), the two 16-lane groups of a half-wave read rows 32 apart.
+template <int WT, bool F8 = false>
+__global__ __launch_bounds__(WT ? 512 : 768) void gemm_tn_grouped256_kernel(typename TnGroupOf<F8>::type gp) {
+    static_assert(!(F8 && WT), "the fp8 form exists for 64 x 64 wave tiles only");
+    constexpr int KROWS = F8 ? 128 : 64;           // rows of the contraction per stage
     constexpr int NMW = WT ? 4 : 8;                // MFMA waves
     constexpr int NI = WT ? 8 : 4;                 // 16-row fragments of A per wave
     __shared__ __attribute__((aligned(16))) char lds[TN2_NST * TN2_STAGE];
@@ -853,7 +874,7 @@ __global__ __launch_bounds__(WT ? 512 : 768) void gemm_tn_grouped256_kernel(TnGr
         const int local = x.tile - gp.pr[pi].tile_begin;
         x.pi = pi;
         x.p0 = (local / gp.pr[pi].tiles_q) * 256; x.q0 = (local % gp.pr[pi].tiles_q) * 128;
-        const int nk = gp.pr[pi].R / 64, mid = nk / 2;
+        const int nk = gp.pr[pi].R / KROWS, mid = nk / 2;
         x.ka = x.half == 1 ? mid : 0; x.kb = x.half == 0 ? mid : nk;
         return true;
     };
@@ -874,8 +895,25 @@ __global__ __launch_bounds__(WT ? 512 : 768) void gemm_tn_grouped256_kernel(TnGr
         auto set_src = [&]() {                                    // advance to the next real item
             Item x;
             do { if (++iss_item >= my_items) return; } while (!item(iss_item, x));
-            const TnProblem& pr = gp.pr[x.pi];
+            const auto& pr = gp.pr[x.pi];
             nk_iss = x.kb - x.ka;
+            if constexpr (F8) {
+                // piece = 8 rows x 128 B of one image: lane (row-in-piece, physical chunk) fetches the logical chunk the swizzle puts there
+                const int prow8 = lane >> 3, slot8 = lane & 7;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    const int pc = 12 * lw + i, img = pc >> 4, q = pc & 15;
+                    const int rloc = 8 * q + prow8;
+                    const int chunk = slot8 ^ (((rloc >> 1) & 3) | (((rloc >> 5) & 1) << 2));
+                    const bool isB = img == 2;
+                    const int64_t ld_b = isB ? pr.ldb_b : pr.lda_b;
+                    int c = (isB ? x.q0 : x.p0 + img * 128) + chunk * 16;
+                    if (c + 16 > ld_b) c = 0;                     // past the leading dimension: clamp
+                    src[i] = (isB ? pr.B : pr.A) + (int64_t)(x.ka * 128 + rloc) * ld_b + c;
+                    step[i] = 128 * ld_b;
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 const int pc = 12 * lw + i, img = pc >> 4, q = pc & 15;
@@ -947,7 +985,7 @@ __global__ __launch_bounds__(WT ? 512 : 768) void gemm_tn_grouped256_kernel(TnGr
     };
     next_item();
     auto store_tile = [&]() {
-        const TnProblem& pr = gp.pr[cx.pi];
+        const auto& pr = gp.pr[cx.pi];
         if (cx.half != 2) {
             // per wave NI x 4 accumulators of 1 KB (64 lanes x 16 B): 16 KB (WT 0) or 32 KB (WT 1: two of the tile's eight slots)
             float* part = (float*)(gp.ws + ((size_t)cx.tile * 8 + wave * (8 / NMW)) * 16384);
@@ -1016,6 +1054,13 @@ __global__ __launch_bounds__(WT ? 512 : 768) void gemm_tn_grouped256_kernel(TnGr
         }
         float* out = pr.out;
         const bool vec = (pr.ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0);
+        if constexpr (F8) {
+            const float sab = pr.sa[0] * pr.sb[0];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] *= sab;
+        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int row = cx.p0 + wp * WROWS + i * 16 + fr;
@@ -1109,6 +1154,47 @@ __global__ __launch_bounds__(WT ? 512 : 768) void gemm_tn_grouped256_kernel(TnGr
                 store_tile();
                 kt = 0;
                 next_item();
+            }
+        }
+    } else if constexpr (F8) {
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        typedef int i32x8 __attribute__((ext_vector_type(8)));
+        typedef __attribute__((address_space(3))) i32x2 lds_i32x2;
+        typedef __attribute__((address_space(3))) char lds_char8;
+        lds_char8* const lbase = (lds_char8*)lds;
+        // lane l of a 16-lane group supplies row (l >> 1), byte 8 (l & 1) of the group's 8 x 16 block; group fg takes rows 32 fg ..
+        // 32 fg + 31 of the stage in four blocks of eight (+ 1024 bytes each): its lane then holds 32 consecutive k of one column
+        const int l16 = lane & 15, swz = ((l16 >> 2) & 3) | ((fg & 1) << 2);
+        const int rowbase = (32 * fg + (l16 >> 1)) * 128 + 8 * (l16 & 1);
+        const int abase = (wp >> 1) * 16384 + rowbase, bbase = 32768 + rowbase;
+        auto frag8 = [&](int a) -> i32x8 {
+            i32x2 v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2*)(lbase + a));
+            i32x2 v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2*)(lbase + a + 1024));
+            i32x2 v2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2*)(lbase + a + 2048));
+            i32x2 v3 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2*)(lbase + a + 3072));
+            return (i32x8){v0[0], v0[1], v1[0], v1[1], v2[0], v2[1], v3[0], v3[1]};
+        };
+        for (int g = 0; g < total; ++g) {
+            const int sb = buf_i * TN2_STAGE;
+            i32x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = frag8(sb + abase + ((((wp & 1) * 4 + i) ^ swz) << 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = frag8(sb + bbase + (((wq * 4 + j) ^ swz) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)      // first operand X (e4m3: cbsz 0), second dY (e5m2: blgp 1), unit block scales
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i], acc[i][j], 0, 1, 0, 0, 0, 0);
+            if (++buf_i == TN2_NST) buf_i = 0;
+            if (++kt == cx.kb - cx.ka) {
+                store_tile();
+                kt = 0;
+                next_item();
+            }
+            if (g + 1 < total) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every read of stage g has returned: the loaders refill its buffer
+                __builtin_amdgcn_s_barrier();
             }
         }
     } else {
@@ -1274,36 +1360,26 @@ extern "C" int64_t dg_gemm_tn_grouped_workspace_bytes(const dg_tn_problem* probl
     return most * (8 * 16384 + 8 * 4) + 16;       // + the sticky error word (last 16 bytes)
 }
 
-extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtype, void* workspace, int64_t workspace_bytes,
-                                  void* stream) {
-    if (!problems || n <= 0) return DG_ERR_ARG;
-    if (dtype != DG_BF16) return DG_ERR_DTYPE;
-    for (int i = 0; i < n; ++i) {
-        const dg_tn_problem& q = problems[i];
-        if (!q.A || !q.B || !q.out || q.R <= 0 || q.P <= 0 || q.Q <= 0 || q.R % 64) return DG_ERR_ARG;
-        if (q.lda % 8 || q.ldb % 8 || !dg_aligned16(q.A) || !dg_aligned16(q.B)) return DG_ERR_ALIGN;
-        if (q.lda < q.P || q.ldb < q.Q || q.ldo < q.Q) return DG_ERR_ARG;
-        if (q.lda >= (1 << 30) || q.ldb >= (1 << 30) || q.ldo >= (1ll << 31)) return DG_ERR_ARG;
-        if (((q.P + 7) / 8) * 8 > q.lda || ((q.Q + 7) / 8) * 8 > q.ldb) return DG_ERR_ARG;
-    }
-    if (workspace && (!dg_aligned16(workspace) || workspace_bytes < dg_gemm_tn_grouped_workspace_bytes(problems, n))) return DG_ERR_ARG;
+template <typename GroupT, typename ProbT, bool F8, int MAXG>
+static int tn_grouped_launch(const dg_tn_problem* problems, int n, void* workspace, hipStream_t s) {
     static const int split_mode = [] { const char* e = getenv("DG_TN_SPLIT"); return e ? atoi(e) : 1; }();   // 0 = never split (A/B runs)
-    hipStream_t s = (hipStream_t)stream;
-    const int tile_p = tn_tile_p();
-    for (int base = 0; base < n; base += TN_MAX_GROUP) {
-        TnGroup gp;
-        gp.n = n - base < TN_MAX_GROUP ? n - base : TN_MAX_GROUP;
+    const int tile_p = F8 ? 256 : tn_tile_p();
+    constexpr int KROWS = F8 ? 128 : 64, ESZ = F8 ? 1 : 2;
+    for (int base = 0; base < n; base += MAXG) {
+        GroupT gp;
+        gp.n = n - base < MAXG ? n - base : MAXG;
         int tiles = 0, nk_min = 1 << 30, nk_max = 0;
         for (int i = 0; i < gp.n; ++i) {
             const dg_tn_problem& q = problems[base + i];
-            TnProblem& t = gp.pr[i];
+            ProbT& t = gp.pr[i];
             t.A = (const char*)q.A; t.B = (const char*)q.B; t.out = q.out;
-            t.lda_b = (int)(q.lda * 2); t.ldb_b = (int)(q.ldb * 2); t.ldo = (int)q.ldo;
+            t.lda_b = (int)(q.lda * ESZ); t.ldb_b = (int)(q.ldb * ESZ); t.ldo = (int)q.ldo;
             t.P = q.P; t.Q = q.Q; t.R = q.R;
+            if constexpr (F8) { t.sa = q.scale_a; t.sb = q.scale_b; }
             t.tiles_q = (q.Q + 127) / 128;
             t.tile_begin = tiles;
             tiles += ((q.P + tile_p - 1) / tile_p) * t.tiles_q;
-            const int nk = q.R / 64;
+            const int nk = q.R / KROWS;
             if (nk < nk_min) nk_min = nk;
             if (nk > nk_max) nk_max = nk;
         }
@@ -1332,11 +1408,37 @@ extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtyp
         }
         const int items = gp.splits == 3 ? tiles : gp.splits * gp.tiles_pad;
         const int grid = items < ncu ? items : ncu;
-        static const int wt_mode = [] { const char* e = getenv("DG_TN_WAVETILE"); return e ? atoi(e) : 0; }();   // 1 = 4 MFMA waves of 128 x 64 (measured 1.8x SLOWER: see the kernel's WT note)
-        if (tile_p == 256 && wt_mode) hipLaunchKernelGGL(gemm_tn_grouped256_kernel<1>, dim3(grid), dim3(512), 0, s, gp);
-        else if (tile_p == 256) hipLaunchKernelGGL(gemm_tn_grouped256_kernel<0>, dim3(grid), dim3(768), 0, s, gp);
-        else hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(tiles < ncu ? tiles : ncu), dim3(768), 0, s, gp);
+        if constexpr (F8) {
+            hipLaunchKernelGGL((gemm_tn_grouped256_kernel<0, true>), dim3(grid), dim3(768), 0, s, gp);
+        } else {
+            static const int wt_mode = [] { const char* e = getenv("DG_TN_WAVETILE"); return e ? atoi(e) : 0; }();   // 1 = 4 MFMA waves of 128 x 64 (measured 1.8x SLOWER: see the kernel's WT note)
+            if (tile_p == 256 && wt_mode) hipLaunchKernelGGL((gemm_tn_grouped256_kernel<1, false>), dim3(grid), dim3(512), 0, s, gp);
+            else if (tile_p == 256) hipLaunchKernelGGL((gemm_tn_grouped256_kernel<0, false>), dim3(grid), dim3(768), 0, s, gp);
+            else hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(tiles < ncu ? tiles : ncu), dim3(768), 0, s, gp);
+        }
         DG_LAUNCH_CHECK();
     }
     return DG_OK;
+}
+
+extern "C" int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtype, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
+    if (!problems || n <= 0) return DG_ERR_ARG;
+    const bool f8 = dtype == DG_FP8_E5M2;         // named after the A operand (dY: e5m2); B (X) is e4m3
+    if (dtype != DG_BF16 && !f8) return DG_ERR_DTYPE;
+    const int g = f8 ? 16 : 8, kr = f8 ? 128 : 64;
+    for (int i = 0; i < n; ++i) {
+        const dg_tn_problem& q = problems[i];
+        if (!q.A || !q.B || !q.out || q.R <= 0 || q.P <= 0 || q.Q <= 0 || q.R % kr) return DG_ERR_ARG;
+        if (q.lda % g || q.ldb % g || !dg_aligned16(q.A) || !dg_aligned16(q.B)) return DG_ERR_ALIGN;
+        if (q.lda < q.P || q.ldb < q.Q || q.ldo < q.Q) return DG_ERR_ARG;
+        if (q.lda >= (1 << 30) || q.ldb >= (1 << 30) || q.ldo >= (1ll << 31)) return DG_ERR_ARG;
+        if (((q.P + g - 1) / g) * g > q.lda || ((q.Q + g - 1) / g) * g > q.ldb) return DG_ERR_ARG;
+        if (f8 && (!q.scale_a || !q.scale_b)) return DG_ERR_ARG;
+    }
+    if (workspace && (!dg_aligned16(workspace) || workspace_bytes < dg_gemm_tn_grouped_workspace_bytes(problems, n))) return DG_ERR_ARG;
+    if (f8 && tn_tile_p() != 256) return DG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (f8) return tn_grouped_launch<TnGroup8, TnProblem8, true, TN_MAX_GROUP8>(problems, n, workspace, s);
+    return tn_grouped_launch<TnGroup, TnProblem, false, TN_MAX_GROUP>(problems, n, workspace, s);
 }

@@ -99,12 +99,25 @@ class FlatSink:
 
     def flush(self, group: int = 0):
         """one grouped launch for everything deferred so far (the whole backward pass, or one layer group of a bucketed
-        data-parallel step: every group has its own problem set, hence its own workspace)"""
+        data-parallel step: every group has its own problem set, hence its own workspace).  precision "fp8": the problems whose
+        two operands exist as fp8 copies by now -- every block Linear: the e5m2 dY its dX GEMM consumed, the e4m3 X its forward
+        GEMM consumed -- go into a second grouped launch on those copies (dg_gemm_tn_grouped, DG_FP8_E5M2)."""
         if self.deferred:
-            ws = self.e.tn_workspaces.get(group)
-            if ws is None:                             # first step: sized for this problem set, zero-filled once
-                ws = self.e.tn_workspaces[group] = ops.gemm_tn_grouped_workspace(self.deferred, self.e.dev)
-            ops.gemm_tn_grouped(self.deferred, ws)
+            bf, f8 = [], []
+            for dy, x, view, P, Q in self.deferred:
+                d8, x8 = getattr(dy, "dg_fp8", None), getattr(x, "dg_fp8x", None)
+                if (self.e.fp8_dw and d8 is not None and x8 is not None and dy.shape[0] % 128 == 0 and d8[0].shape == (dy.shape[0], P)
+                        and x8[0].shape == (x.shape[0], Q) and P % 16 == 0 and Q % 16 == 0):
+                    f8.append((d8[0], x8[0], view, P, Q, d8[1], x8[1]))
+                else:
+                    bf.append((dy, x, view, P, Q))
+            for kind, probs in ((0, bf), (1, f8)):
+                if not probs:
+                    continue
+                ws = self.e.tn_workspaces.get((group, kind))
+                if ws is None:                         # first step: sized for this problem set, zero-filled once
+                    ws = self.e.tn_workspaces[(group, kind)] = ops.gemm_tn_grouped_workspace(probs, self.e.dev)
+                ops.gemm_tn_grouped(probs, ws)
             self.deferred = []
         for slab, n, splits, out in self.small_pending:
             ops.reduce_partials(slab, n, splits, out, n)
@@ -149,7 +162,7 @@ class TrainEngine:
     def __init__(self, model: TransformerLM, batch_size: int, context_length: Optional[int] = None, *,
                  lr: float = 1e-3, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-2,
                  seed: int = 42, rank: int = 0, world_size: int = 1, process_group=None, use_graph: bool = True,
-                 dp_buckets: Optional[int] = None, logits: str = "auto", grad_stream: str = "auto"):
+                 dp_buckets: Optional[int] = None, logits: str = "auto", grad_stream: str = "auto", fp8_dw: Optional[bool] = None):
         if not isinstance(model, TransformerLM):
             raise TypeError("TrainEngine drives TransformerLM (the other five models train through the autograd path)")
         p0 = next(model.parameters())
@@ -210,6 +223,8 @@ class TrainEngine:
         # FFN2 + residual + the next block's LN1): bf16 mode at the width the kernel is built for.  OFF by default (DG_CHAIN_LN=1 turns
         # it on): measured inside the captured step (round 3, same box) proj + LN2 24.7 us against 17.4 + 8.8, FFN2 + LN1' 44.2 us
         # against 33.5 + 8.8, plus 7.8 us for the packed-weight refresh: 2.558 vs 2.528 ms per step
+        # precision "fp8": the weight gradients of the block Linears on the fp8 copies of their operands (DG_FP8_DW=0: bf16 dW, A/B)
+        self.fp8_dw = self.fp8 and (_os.environ.get("DG_FP8_DW", "1") != "0" if fp8_dw is None else bool(fp8_dw))
         self.chain_ln = (_os.environ.get("DG_CHAIN_LN", "0") == "1" and not self.fp8 and self.NH * self.H == self.C
                          and ops.block_chain_supported(self.M, self.C, self.act))
         self._build_layout()

@@ -396,33 +396,46 @@ def gemm_tn(A: Tensor, Bm: Tensor, out_part: Tensor, split_stride: int, n_splits
 
 
 def _tn_problem_array(problems):
+    """problems: (A, B, out, P, Q) with bf16 operands, or (A e5m2, B e4m3, out, P, Q, scale_a, scale_b).  Returns (array, dtype code)"""
     from ._lib import TnProblem
     arr = (TnProblem * len(problems))()
-    for t, (A, Bm, out, P, Q) in zip(arr, problems):
-        _chk(A, "A", torch.bfloat16, contiguous=False)
-        _chk(Bm, "B", torch.bfloat16, contiguous=False)
+    f8 = len(problems[0]) == 7
+    for t, pr in zip(arr, problems):
+        if (len(pr) == 7) != f8:
+            raise RuntimeError("gemm_tn_grouped: bf16 and fp8 problems go into separate calls")
+        A, Bm, out, P, Q = pr[:5]
+        if f8:
+            _chk(A, "A", torch.float8_e5m2, contiguous=False)
+            _chk(Bm, "B", torch.float8_e4m3fn, contiguous=False)
+            _chk(pr[5], "scale_a", torch.float32)
+            _chk(pr[6], "scale_b", torch.float32)
+            t.scale_a, t.scale_b = _p(pr[5]), _p(pr[6])
+        else:
+            _chk(A, "A", torch.bfloat16, contiguous=False)
+            _chk(Bm, "B", torch.bfloat16, contiguous=False)
         _chk(out, "out", torch.float32, contiguous=False)
         if A.shape[0] != Bm.shape[0] or out.numel() < P * Q:
             raise RuntimeError("gemm_tn_grouped: operand mismatch")
         t.A, t.lda, t.B, t.ldb, t.out, t.ldo = _p(A), _ld(A), _p(Bm), _ld(Bm), _p(out), Q
         t.R, t.P, t.Q, t.reserved = A.shape[0], P, Q, 0
-    return arr
+    return arr, (DG_FP8_E5M2 if f8 else DG_BF16)
 
 
 def gemm_tn_grouped_workspace(problems, device) -> Tensor:
     """zero-filled split-K workspace for gemm_tn_grouped on these problems (allocate once, pass to every call)"""
-    arr = _tn_problem_array(problems)
+    arr, _ = _tn_problem_array(problems)
     return torch.zeros(max(16, int(lib.dg_gemm_tn_grouped_workspace_bytes(arr, len(problems)))), dtype=torch.uint8, device=device)
 
 
 def gemm_tn_grouped(problems, workspace: Optional[Tensor] = None) -> None:
     """every dW of a backward pass in one launch: problems = [(A [R,>=P], B [R,>=Q], out [P,Q] fp32, P, Q), ...];
-    out_i = A_i[:, :P]^T B_i[:, :Q] over all R rows (bf16 operands, R % 64 == 0).  The caller keeps the operands alive.
+    out_i = A_i[:, :P]^T B_i[:, :Q] over all R rows (bf16 operands, R % 64 == 0).  fp8 form: [(A e5m2, B e4m3, out, P, Q,
+    scale_a [1], scale_b [1]), ...] with R % 128 == 0: out_i = scale_a * scale_b * A_i^T B_i.  The caller keeps the operands alive.
     `workspace` (gemm_tn_grouped_workspace) lets the kernel split the contraction of every tile in two."""
-    arr = _tn_problem_array(problems)
+    arr, code = _tn_problem_array(problems)
     if workspace is not None:
         _chk(workspace, "workspace", torch.uint8)
-    check(lib.dg_gemm_tn_grouped(arr, len(problems), dt_code(torch.bfloat16), _p(workspace) if workspace is not None else None,
+    check(lib.dg_gemm_tn_grouped(arr, len(problems), code, _p(workspace) if workspace is not None else None,
                                  workspace.numel() if workspace is not None else 0, _stream()), "dg_gemm_tn_grouped")
 
 

@@ -203,6 +203,7 @@ def linear_nt(run: Run, x: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: 
     if run.fp8 and fp8_k_ok(W.shape[1]) and x.is_contiguous() and x.dtype == torch.bfloat16:
         wq, ws = run.weights.fwd8(W)
         xq, xs = x8 if x8 is not None else _quantize_operand(run, x, E4M3, fp8_site)
+        x.dg_fp8x = (xq, xs)        # the e4m3 copy travels with the activation: it is also the X operand of this Linear's fp8 dW
         return ops.gemm_nt(xq, wq, out_dtype, scale_a=xs, scale_b=ws, **epi)
     return ops.gemm_nt(x, run.weights.fwd(W), out_dtype, **epi)
 
@@ -228,6 +229,7 @@ def linear_dx(run: Run, g: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: 
             if g8 is None:
                 g8 = getattr(g, "dg_fp8", None)         # left by the fused LayerNorm backward that produced g (see _ln_tail)
             gq, gs = g8 if g8 is not None else _quantize_operand(run, g, E5M2, fp8_site)
+            g.dg_fp8 = (gq, gs)     # (also the dY operand of this Linear's fp8 dW, looked up when the grouped launch is assembled)
             return ops.gemm_nt(gq, wq, out_dtype, K=K, scale_a=gs, scale_b=ws, **epi)
     return ops.gemm_nt(g, run.weights.bwd(W), out_dtype, K=K, **epi)
 

@@ -45,7 +45,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 13   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 14   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -222,13 +222,18 @@ int dg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb,
  * contraction (no split, no partial slabs, no reduction pass): out_i[P_i,Q_i] = sum_r A_i[r,P_i] * B_i[r,Q_i].
  * The 128x128 output tiles of all problems are dealt to persistent workgroups, so the step's ~25 small dW
  * GEMMs (ref: autograd of every nn.Linear, src/model_component.py:321-323,392-393,454, src/model.py:599) fill
- * the chip together at the end of backward.  bf16 operands only; R_i must be a multiple of 64; alignment as
- * for dg_gemm_tn.  The operands must stay alive until this call (the caller keeps dY of every Linear). */
+ * the chip together at the end of backward.  dtype DG_BF16: bf16 operands, R_i a multiple of 64, alignment as for dg_gemm_tn.
+ * dtype DG_FP8_E5M2 (precision "fp8"): A = dY as OCP e5m2, B = X as OCP e4m3 -- the very copies the fp8 dX / forward GEMMs
+ * consumed -- one byte per element, R_i a multiple of 128, lda / ldb multiples of 16, scale_a / scale_b the dequantisation
+ * factors dg_fp8_quantize* left for them; fp32 accumulation, v_mfma_f32_16x16x128_f8f6f4.
+ * The operands must stay alive until this call (the caller keeps dY of every Linear). */
 typedef struct dg_tn_problem {
     const void* A; int64_t lda;     /* dY [R,P] */
     const void* B; int64_t ldb;     /* X  [R,Q] */
     float* out; int64_t ldo;        /* dW [P,Q] fp32, overwritten */
     int R, P, Q, reserved;
+    const float* scale_a;           /* fp8 operands only: device scalars, dW = scale_a[0] * scale_b[0] * sum_r qA qB */
+    const float* scale_b;
 } dg_tn_problem;
 int dg_gemm_tn_grouped(const dg_tn_problem* problems, int n, int dtype, void* workspace, int64_t workspace_bytes, void* stream);
 /* Optional workspace (device memory of dg_gemm_tn_grouped_workspace_bytes(problems, n) bytes, zero-filled ONCE by the
