@@ -18,7 +18,7 @@ DG_F32 = 0
 DG_BF16 = 1
 DG_FP8_E4M3 = 2
 DG_FP8_E5M2 = 3
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class GemmNtArgs(C.Structure):
@@ -115,6 +115,7 @@ SIGNATURES = {
     "dg_attn_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
     "dg_attn_decode": [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dg_cross_entropy": [_vp, _i, _i64, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _i, _vp],
+    "dg_cross_entropy_fp8": [_vp, _i64, _vp, _vp, _vp, _i64, _f, _i, _i, _vp, _i64, _vp],
     "dg_cross_entropy_fused": [_vp, _i64, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp, _i64, _i, _vp, _vp, _vp, _f, _vp],
     "dg_reduce_sum": [_vp, _i64, _f, _vp, _vp],
     "dg_softmax_rows": [_vp, _i64, _vp, _i64, _i, _i, _vp],

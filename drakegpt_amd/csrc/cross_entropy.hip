@@ -238,9 +238,13 @@ __global__ __launch_bounds__(CE_BLOCK) void cross_entropy_row_kernel(const TL* l
 // registers TWO workgroups are resident per CU and one's loads run beside the other's stores (one resident workgroup
 // alternated between a load phase and a store phase: 570 us = 2.9 TB/s at M = 8192, V = 50257).  The exponentials are
 // computed twice (sum pass, gradient pass) -- 0.8 G quarter-rate instructions, ~25 us of a kernel that moves 1.65 GB.
+// q8 (nullable; round 3, precision "fp8"): the gradient a second time as OCP e5m2 with the A-PRIORI scale q8_scale = 57344 /
+// grad_scale (|softmax - onehot| <= 1, so |dlogits| <= grad_scale: no amax pass, no history) -- the A operand of lm_head's fp8 dX
+// GEMM and the dY operand of its fp8 dW; columns V .. ldq8 - 1 are written as zeros (the dX contraction runs over the padded width).
 __global__ __launch_bounds__(CE_BLOCK, 8) void cross_entropy_row_bf16_kernel(const bf16_t* logits, int64_t ldl, const int64_t* __restrict__ targets,
                                                                               float* __restrict__ loss_rows, bf16_t* dlogits, int64_t ldd,
-                                                                              float grad_scale, const float* __restrict__ gs_dev, int M, int V) {
+                                                                              float grad_scale, const float* __restrict__ gs_dev, int M, int V,
+                                                                              unsigned char* __restrict__ q8, int64_t ldq8, float q8_scale) {
     __shared__ float red[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int row = blockIdx.x;
@@ -295,19 +299,50 @@ __global__ __launch_bounds__(CE_BLOCK, 8) void cross_entropy_row_bf16_kernel(con
             const int c = tid + CE_BLOCK * j;
             if (c < dchunk) {
                 bf16x8 o;
+                float gv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int i = c * 8 + e;
-                    o[e] = (bf16_t)(i < V ? (expf((float)q[j][e] - mx) * inv - (i == (int)t ? 1.f : 0.f)) * grad_scale : 0.f);
+                    gv[e] = i < V ? (expf((float)q[j][e] - mx) * inv - (i == (int)t ? 1.f : 0.f)) * grad_scale : 0.f;
+                    o[e] = (bf16_t)gv[e];
                 }
                 *(bf16x8*)(d + c * 8) = o;
+                if (q8 && c * 8 < ldq8) {                                 // (uniform per launch; ldq8 % 8 == 0)
+                    int lo = 0, hi = 0;
+                    lo = __builtin_amdgcn_cvt_pk_bf8_f32(gv[0] * q8_scale, gv[1] * q8_scale, lo, false);
+                    lo = __builtin_amdgcn_cvt_pk_bf8_f32(gv[2] * q8_scale, gv[3] * q8_scale, lo, true);
+                    hi = __builtin_amdgcn_cvt_pk_bf8_f32(gv[4] * q8_scale, gv[5] * q8_scale, hi, false);
+                    hi = __builtin_amdgcn_cvt_pk_bf8_f32(gv[6] * q8_scale, gv[7] * q8_scale, hi, true);
+                    typedef int i32x2 __attribute__((ext_vector_type(2)));
+                    *(i32x2*)(q8 + (int64_t)row * ldq8 + c * 8) = (i32x2){lo, hi};
+                }
             }
         }
     }
 }
 
+static int ce_launch(const void* logits_v, int logits_dtype, int64_t ldl, const int64_t* targets, float* loss_rows,
+                     void* dlogits, int64_t ldd, int dtype, float grad_scale, const float* grad_scale_dev, int M, int V,
+                     unsigned char* q8, int64_t ldq8, float q8_scale, void* stream);
+
 extern "C" int dg_cross_entropy(const void* logits_v, int logits_dtype, int64_t ldl, const int64_t* targets, float* loss_rows,
                                 void* dlogits, int64_t ldd, int dtype, float grad_scale, const float* grad_scale_dev, int M, int V, void* stream) {
+    return ce_launch(logits_v, logits_dtype, ldl, targets, loss_rows, dlogits, ldd, dtype, grad_scale, grad_scale_dev, M, V, nullptr, 0, 0.f, stream);
+}
+
+// bf16 logits (the whole-row kernel, 16-byte accesses) with the gradient ALSO as e5m2: dlogits_fp8 [M, ld8] = e5m2(dlogits * 57344 /
+// grad_scale), dequantisation factor grad_scale / 57344 (a constant the caller knows); ld8 % 16 == 0, ld8 >= V, columns beyond V zero
+extern "C" int dg_cross_entropy_fp8(const void* logits, int64_t ldl, const int64_t* targets, float* loss_rows, void* dlogits, int64_t ldd,
+                                    float grad_scale, int M, int V, void* dlogits_fp8, int64_t ld8, void* stream) {
+    if (!dlogits || !dlogits_fp8 || ld8 < V || ld8 % 16 || ld8 > ldd || !dg_aligned16(dlogits_fp8) || !(grad_scale > 0.f)) return DG_ERR_ARG;
+    if (ldl % 8 || ldd % 8 || !dg_aligned16(logits) || !dg_aligned16(dlogits) || (int64_t)((V + 7) / 8) * 8 > ldl) return DG_ERR_ALIGN;
+    return ce_launch(logits, DG_BF16, ldl, targets, loss_rows, dlogits, ldd, DG_BF16, grad_scale, nullptr, M, V, (unsigned char*)dlogits_fp8, ld8,
+                     57344.f / grad_scale, stream);
+}
+
+static int ce_launch(const void* logits_v, int logits_dtype, int64_t ldl, const int64_t* targets, float* loss_rows,
+                     void* dlogits, int64_t ldd, int dtype, float grad_scale, const float* grad_scale_dev, int M, int V,
+                     unsigned char* q8, int64_t ldq8, float q8_scale, void* stream) {
     if (!logits_v || !targets || !loss_rows || M <= 0 || V <= 0 || ldl < V) return DG_ERR_ARG;
     if (dlogits && ldd < V) return DG_ERR_ARG;
     if (logits_dtype != DG_F32 && logits_dtype != DG_BF16) return DG_ERR_DTYPE;
@@ -319,9 +354,10 @@ extern "C" int dg_cross_entropy(const void* logits_v, int logits_dtype, int64_t 
         if (dlogits == logits_v && ldd != ldl) return DG_ERR_ARG;
         const bool vec = ldl % 8 == 0 && dg_aligned16(logits_v) && (!dlogits || (ldd % 8 == 0 && dg_aligned16(dlogits))) &&
                          (int64_t)((V + 7) / 8) * 8 <= ldl && w <= (int64_t)CE_BLOCK * CE_MAXC * 8;
+        if (q8 && !vec) return DG_ERR_ARG;
         if (vec)
             hipLaunchKernelGGL(cross_entropy_row_bf16_kernel, dim3(M), dim3(CE_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)logits_v, ldl,
-                               targets, loss_rows, (bf16_t*)dlogits, ldd, grad_scale, grad_scale_dev, M, V);
+                               targets, loss_rows, (bf16_t*)dlogits, ldd, grad_scale, grad_scale_dev, M, V, q8, ldq8, q8_scale);
         else
             hipLaunchKernelGGL((cross_entropy_row_kernel<bf16_t, bf16_t>), dim3(M), dim3(CE_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)logits_v, ldl,
                                targets, loss_rows, (bf16_t*)dlogits, ldd, grad_scale, grad_scale_dev, M, V);

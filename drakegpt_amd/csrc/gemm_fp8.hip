@@ -16,6 +16,7 @@ int dg_gemm_nt_fp8_launch(const NtParams& p, int f8, int out_dtype, bool pf, boo
         else if (epi == 8) L(bf16_t, false, NJ_, 8, 1); \
         else if (epi == 3 && ob) L(bf16_t, false, NJ_, 3, 1); \
         else if (epi == 3) L(float, false, NJ_, 3, 1); \
+        else if (epi == 5 && ob) L(bf16_t, false, NJ_, 5, 1); \
         else if (epi == 7 && ob) L(bf16_t, false, NJ_, 7, 1); \
         else if (epi == 7) L(float, false, NJ_, 7, 1); \
         else if (ob) L(bf16_t, false, NJ_, 0, 1); \

@@ -55,6 +55,11 @@ class _Layout:
         return off
 
 
+def _os_env(name: str, default: str) -> str:
+    import os
+    return os.environ.get(name, default)
+
+
 class ShadowWeights:
     """persistent GEMM operands: bf16 (or the fp32 master itself) for forward, W^T for dX"""
 
@@ -107,7 +112,7 @@ class FlatSink:
             for dy, x, view, P, Q in self.deferred:
                 d8, x8 = getattr(dy, "dg_fp8", None), getattr(x, "dg_fp8x", None)
                 if (self.e.fp8_dw and d8 is not None and x8 is not None and dy.shape[0] % 128 == 0 and d8[0].shape == (dy.shape[0], P)
-                        and x8[0].shape == (x.shape[0], Q) and P % 16 == 0 and Q % 16 == 0):
+                        and x8[0].shape == (x.shape[0], Q) and ops._ld(d8[0]) % 16 == 0 and ops._ld(x8[0]) % 16 == 0):
                     f8.append((d8[0], x8[0], view, P, Q, d8[1], x8[1]))
                 else:
                     bf.append((dy, x, view, P, Q))
@@ -224,6 +229,8 @@ class TrainEngine:
         # it on): measured inside the captured step (round 3, same box) proj + LN2 24.7 us against 17.4 + 8.8, FFN2 + LN1' 44.2 us
         # against 33.5 + 8.8, plus 7.8 us for the packed-weight refresh: 2.558 vs 2.528 ms per step
         # precision "fp8": the weight gradients of the block Linears on the fp8 copies of their operands (DG_FP8_DW=0: bf16 dW, A/B)
+        self.last_block_act = _os.environ.get("DG_LAST_BLOCK_ACT", "1") != "0"      # 0: fp32 output + cast launch (A/B runs)
+        self.fp8_head = False       # (set in _alloc_and_adopt: precision fp8 at a large vocabulary)
         self.fp8_dw = self.fp8 and (_os.environ.get("DG_FP8_DW", "1") != "0" if fp8_dw is None else bool(fp8_dw))
         self.chain_ln = (_os.environ.get("DG_CHAIN_LN", "0") == "1" and not self.fp8 and self.NH * self.H == self.C
                          and ops.block_chain_supported(self.M, self.C, self.act))
@@ -242,12 +249,12 @@ class TrainEngine:
         self.x = torch.zeros((self.B, self.T), dtype=torch.int64, device=self.dev)
         self.y = torch.zeros((self.B, self.T), dtype=torch.int64, device=self.dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=self.dev)
+        # fp8 head: dequantisation factor of the e5m2 dlogits the loss kernel writes with the a-priori scale 57344 M (|dlogits| <= 1 / M)
+        self.dl_scale = torch.full((1,), 1.0 / (self.M * 57344.0), dtype=torch.float32, device=self.dev)
         self.loss_scratch = torch.zeros((2048 + 1,), dtype=torch.float32, device=self.dev)     # fused loss head: shares + arrival counter
         self.corpus: Optional[Tensor] = None
         self._graphs = None
         self._eval_graph = None
-        import os
-        self.last_block_act = os.environ.get("DG_LAST_BLOCK_ACT", "1") != "0"      # 0: fp32 output + cast launch (A/B runs)
         self.force_dp_path = False      # rehearsal hook (tools/dp_rccl_smoke.py): take the multi-rank path with one rank
         self.debug_timing = False       # multi-rank step only: HIP events around backward graph(s) / exchange / optimizer graph -> last_timing (ms)
         self.last_timing: Optional[dict] = None
@@ -428,7 +435,11 @@ class TrainEngine:
         if self.fp8:
             self.shadow8 = torch.zeros(self.layA.size, dtype=S.E4M3, device=dev)
             self.wt8_flat = torch.zeros(self.wt_flat.numel(), dtype=S.E4M3, device=dev)
-            n_fp8 = sum(1 for key in self.layA.entries if key != "lm.w")
+            # lm_head joins when its two contraction lengths suit the fp8 K step: K = C forward, K = V padded (50257 -> 50304 = 393 x
+            # 128) in the dX direction; a char-level vocabulary (80 -> 128 columns of padding) stays bf16
+            self.fp8_head = (_os_env("DG_FP8_HEAD", "1") != "0" and self.bf16_logits and S.fp8_k_ok(self.C) and S.fp8_k_ok(S.k_pad(self.V, self.act))
+                             and self.last_block_act)
+            n_fp8 = sum(1 for key in self.layA.entries if key != "lm.w" or self.fp8_head)
             self.wscale_f = torch.ones(n_fp8, dtype=torch.float32, device=dev)
             self.wscale_b = torch.ones(n_fp8, dtype=torch.float32, device=dev)
         self.wpack_flat = torch.zeros(self.layA.size, dtype=torch.bfloat16, device=dev) if self.chain_ln else None
@@ -448,7 +459,7 @@ class TrainEngine:
             Wt = self.wt_flat[wt_off:wt_off + wt_sizes[key]].view(wt_shape)
             self.weights.bwd_map[W.data_ptr()] = Wt
             self._mats.append((W, Wt))
-            if self.fp8 and key != "lm.w":                       # lm_head stays bf16 (V is no multiple of the fp8 K step)
+            if self.fp8 and (key != "lm.w" or self.fp8_head):
                 i = len(seg_f)
                 seg_f.append([off, n])
                 seg_b.append([wt_off, wt_sizes[key]])
@@ -526,6 +537,22 @@ class TrainEngine:
             # a whole row in registers and overwrites it in place with its gradient (1.65 GB less written and 0.82 GB less read
             # per step at the GPT-2 vocabulary, M = 8192, than fp32 logits + a separate bf16 gradient)
             buf = torch.empty((M, S.k_pad(self.V, self.act)), dtype=self.act, device=self.dev)
+            if self.fp8_head and run.fp8 and h.dtype == torch.bfloat16:
+                # precision fp8 (round 3): lm_head's three contractions on the fp8 MFMA too.  Forward on e4m3 x e4m3; the loss kernel
+                # leaves its gradient a second time as e5m2 (a-priori scale: |dlogits| <= 1 / M) -- operand of the dX GEMM and of the
+                # weight gradient (the bf16 gradient in `buf` still feeds the bias column sums)
+                Wl = self.param_view("lm.w")
+                xq, xs = S._quantize_operand(run, h, S.E4M3, "lm.x")
+                h.dg_fp8x = (xq, xs)
+                wq, ws = self.weights.fwd8(Wl)
+                logits = ops.gemm_nt(xq, wq, self.act, scale_a=xs, scale_b=ws, bias=self.param_view("lm.b"), out=buf[:, :self.V])
+                if want_grad and M == self.M:
+                    q8 = torch.empty((M, buf.shape[1]), dtype=S.E5M2, device=self.dev)
+                    rows = ops.cross_entropy_fp8(logits, y_idx.view(M), self.V, buf, 1.0 / M, q8)
+                    buf.dg_q8 = (q8, self.dl_scale)
+                else:
+                    rows = ops.cross_entropy(logits, y_idx.view(M), self.V, dlogits=buf if want_grad else None, grad_scale=1.0 / M)
+                return None, rows, (saved, h, buf)
             logits, (xa,) = S.linear_fwd(run, h, self.param_view("lm.w"), self.param_view("lm.b"), out=buf[:, :self.V])
             rows = ops.cross_entropy(logits, y_idx.view(M), self.V, dlogits=buf if want_grad else None, grad_scale=1.0 / M)
             return None, rows, (saved, xa, buf)
@@ -548,7 +575,11 @@ class TrainEngine:
         saved, xa, dlogits = ctx[:3]
         head_done = len(ctx) > 3            # the fused loss head already left the lm_head bias partials (and the loss) behind
         st = dict(run=run, x_idx=x_idx, saved=saved, sink=FlatSink(self), g_next=None, g0=None)
-        st["dh"] = S.linear_bwd_from_act(run, (xa,), dlogits[:, :self.V], self.param_view("lm.w"), True, st["sink"], {"w": "lm.w", "b": "lm.b"},
+        g = dlogits[:, :self.V]
+        q8 = getattr(dlogits, "dg_q8", None)
+        if q8 is not None:
+            g.dg_fp8 = (q8[0][:, :self.V], q8[1])          # the e5m2 copy the loss kernel left (fp8 head)
+        st["dh"] = S.linear_bwd_from_act(run, (xa,), g, self.param_view("lm.w"), True, st["sink"], {"w": "lm.w", "b": "lm.b"},
                                          bias_done=head_done)
         return st
 

@@ -558,6 +558,20 @@ def cross_entropy(logits: Tensor, targets: Tensor, V: int, dlogits: Optional[Ten
     return loss_rows
 
 
+def cross_entropy_fp8(logits: Tensor, targets: Tensor, V: int, dlogits: Tensor, grad_scale: float, dlogits_fp8: Tensor) -> Tensor:
+    """cross_entropy on bf16 logits (gradient in bf16, possibly in place) that also writes the gradient as e5m2 with the a-priori
+    scale 57344 / grad_scale into dlogits_fp8 [M, ld8 >= V] (pad columns zeroed); dequantisation factor: grad_scale / 57344"""
+    _chk(logits, "logits", torch.bfloat16, contiguous=False)
+    _chk(targets, "targets", torch.int64)
+    _chk(dlogits, "dlogits", torch.bfloat16, contiguous=False)
+    _chk(dlogits_fp8, "dlogits_fp8", torch.float8_e5m2, contiguous=False)
+    M = logits.shape[0]
+    loss_rows = torch.empty((M,), dtype=torch.float32, device=logits.device)
+    check(lib.dg_cross_entropy_fp8(_p(logits), _ld(logits), _p(targets), _p(loss_rows), _p(dlogits), _ld(dlogits), float(grad_scale), M, V,
+                                   _p(dlogits_fp8), _ld(dlogits_fp8), _stream()), "dg_cross_entropy_fp8")
+    return loss_rows
+
+
 def cross_entropy_fused_supported(logits: Tensor, dlogits: Tensor, n_partials: int) -> bool:
     return logits.dtype == torch.float32 and _ld(dlogits) <= 128 and 0 < n_partials <= 2048
 

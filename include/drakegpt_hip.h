@@ -45,7 +45,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 14   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 15   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -321,6 +321,13 @@ int dg_cross_entropy(const void* logits, int logits_dtype, int64_t ldl, const in
                      void* dlogits, int64_t ldd, int dtype, float grad_scale,
                      const float* grad_scale_dev /* nullable: multiplies grad_scale */,
                      int M, int V, void* stream);
+/* dg_cross_entropy on bf16 logits (large vocabularies, gradient written in place or elsewhere in bf16) that ALSO leaves the
+ * gradient as OCP e5m2 for precision "fp8": dlogits_fp8 [M, ld8] = e5m2(dlogits * 57344 / grad_scale) -- |softmax - onehot| <= 1
+ * bounds |dlogits| by grad_scale, so the scale is known a priori (no amax pass, no history) and the consumer's dequantisation
+ * factor is the constant grad_scale / 57344.  ld8 % 16 == 0, V <= ld8 <= ldd; columns V .. ld8 - 1 are written as zeros (the dX
+ * contraction of lm_head runs over the padded width).  ref: F.cross_entropy at src/model.py:604-607. */
+int dg_cross_entropy_fp8(const void* logits, int64_t ldl, const int64_t* targets, float* loss_rows, void* dlogits, int64_t ldd,
+                         float grad_scale, int M, int V, void* dlogits_fp8, int64_t ld8, void* stream);
 /* The loss head of a captured step at a small vocabulary (ldd <= 128, fp32 logits): dg_cross_entropy + the column sums of
  * the gradient (lm_head bias gradient: partial row b of colsum_part = rows [b * ceil(M / n_partials), ...), fp32, nullable) +
  * the scalar loss (loss_out[0] = loss_scale * sum of loss_rows, added in a fixed order by the workgroup that finishes last;

@@ -476,7 +476,7 @@ def test_gpt2_medium_shape_fp8_engine_steps(dev):
         torch.cuda.synchronize()
         eng.check_status()
         if prec == "fp8":
-            assert len(eng.fp8_sites) == 8 * L                 # every Linear of every block, forward and dX operands
+            assert len(eng.fp8_sites) == 8 * L + int(eng.fp8_head)     # every Linear of every block, forward and dX operands (+ the input of the fp8 lm_head)
         grads = {k: v.detach().clone() for k, v in eng.named_grads().items()}
         l1 = eng.step().item()                                 # same batch again, after one AdamW step: a graph replay
         assert math.isfinite(l0) and math.log(V) - 0.5 < l0 < math.log(V) + 3.0, l0
@@ -596,3 +596,69 @@ def test_gemm_tn_grouped_fp8(dev, with_short):
     with pytest.raises(RuntimeError):                   # the two operand kinds do not mix in one launch
         ops.gemm_tn_grouped([(z8a[:128], z8b[:128], torch.zeros(64 * 64, device=dev), 64, 64, one, one),
                              (z8a[:128].bfloat16(), z8b[:128].bfloat16(), torch.zeros(64 * 64, device=dev), 64, 64)])
+
+
+def test_cross_entropy_fp8_gradient_copy(dev):
+    """round 3 (fp8 lm_head): the loss kernel on bf16 logits writes its gradient in place (bf16) AND as e5m2 with the a-priori scale
+    57344 / grad_scale -- |softmax - onehot| <= 1 bounds |dlogits| by grad_scale (ref: F.cross_entropy, src/model.py:604-607).  The
+    e5m2 copy times grad_scale / 57344 is the fp64 gradient to e5m2 rounding (2^-3 relative per element, far less in norm), equals the
+    OCP rounding of the very value the bf16 path rounds, pad columns are zero, losses and the bf16 gradient are those of
+    dg_cross_entropy."""
+    from drakegpt_amd import ops
+    M, V, ld = 64, 50257, 50304
+    g = torch.Generator().manual_seed(3)
+    buf = torch.zeros(M, ld, dtype=torch.bfloat16)
+    buf[:, :V] = (torch.randn(M, V, generator=g) * 3).bfloat16()
+    tgt = torch.randint(0, V, (M,), generator=g)
+    x = buf[:, :V].double()
+    ref = (torch.softmax(x, 1) - torch.nn.functional.one_hot(tgt, V)) / M
+    ref_rows = torch.logsumexp(x, 1) - x[torch.arange(M), tgt]
+    a, b = buf.to(dev), buf.to(dev)
+    rows0 = ops.cross_entropy(a[:, :V], tgt.to(dev), V, dlogits=a, grad_scale=1.0 / M)
+    q8 = torch.full((M, ld), 7.0, device=dev).to(torch.float8_e5m2)
+    rows1 = ops.cross_entropy_fp8(b[:, :V], tgt.to(dev), V, b, 1.0 / M, q8)
+    torch.cuda.synchronize()
+    assert torch.equal(rows0, rows1) and torch.equal(a, b) and rel(rows1, ref_rows) < 1e-6
+    deq = q8.float().cpu().double() * (1.0 / M / 57344.0)
+    assert torch.all(deq[:, V:] == 0)
+    assert rel(deq[:, :V], ref) < 4e-2, rel(deq[:, :V], ref)
+    el = ((deq[:, :V] - ref).abs() / ref.abs().clamp_min(1e-30))
+    big = ref.abs() > 1e-4 / M                     # above e5m2's subnormal range at this scale
+    assert el[big].max().item() <= 2 ** -3 * 1.02, el[big].max().item()
+    with pytest.raises(RuntimeError):              # ld8 must be a multiple of 16 and within the gradient's leading dimension
+        ops.cross_entropy_fp8(b[:, :V], tgt.to(dev), V, b, 1.0 / M, torch.zeros((M, 50264), device=dev).to(torch.float8_e5m2))
+
+
+def test_fp8_head_engine_step(dev):
+    """the fp8 lm_head inside the engine (V 50257, T 1024, C 1024, L 1, B 1): forward on e4m3 x e4m3, dX on the loss kernel's e5m2
+    gradient x the e4m3 W^T shadow (K = 50304), dW in the fp8 grouped launch -- against the same engine with the bf16 head
+    (DG_FP8_HEAD=0): loss, the head's gradients and the gradient that enters the blocks."""
+    import os
+    import drakegpt_amd as D
+    from drakegpt_amd.engine import TrainEngine
+    V, C, T, NH, L, B = 50257, 1024, 1024, 16, 1, 1
+    g = torch.Generator().manual_seed(8)
+    x = torch.randint(0, V, (B, T), generator=g).to(dev)
+    y = torch.randint(0, V, (B, T), generator=g).to(dev)
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["DG_FP8_HEAD"] = mode
+        try:
+            torch.manual_seed(42)
+            m = D.TransformerLM(V, C, T, NH, L, 0.0, precision="fp8").to(dev).train()
+            eng = TrainEngine(m, B, T, lr=1e-4, seed=3, use_graph=True)
+        finally:
+            os.environ.pop("DG_FP8_HEAD", None)
+        assert eng.fp8_head == (mode == "1") and eng.bf16_logits
+        eng.set_batch(x, y)
+        loss = eng.step().item()
+        torch.cuda.synchronize()
+        eng.check_status()
+        out[mode] = (loss, {k: v.detach().float().clone() for k, v in eng.named_grads().items()})
+    (l1, g1), (l0, g0) = out["1"], out["0"]
+    e = {k: rel(g1[k], g0[k]) for k in ("lm_head.weight", "lm_head.bias", "blocks.0.ffwd.net.2.weight", "blocks.0.sa_head.proj.weight")}
+    if os.environ.get("DG_TEST_REPORT"):
+        print(f"[parity] fp8 head vs bf16 head: loss {abs(l1 - l0) / l0:.2e}, " + ", ".join(f"{k} {v:.2e}" for k, v in e.items()), flush=True)
+    # measured (round 3): loss 1.5e-5, lm_head.weight 2.7e-2, lm_head.bias 3.5e-4, block gradients 6.1e-2 / 6.7e-2 (e5m2 dlogits: 2 mantissa bits)
+    assert abs(l1 - l0) < 2e-3 * l0 and e["lm_head.weight"] < 0.1 and e["lm_head.bias"] < 2e-2
+    assert e["blocks.0.ffwd.net.2.weight"] < 0.15 and e["blocks.0.sa_head.proj.weight"] < 0.15, e
