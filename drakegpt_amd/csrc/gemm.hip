@@ -639,7 +639,7 @@ struct TnProblem {
     int P, Q, R, tiles_q, tile_begin;
 };
 // ws (256-row-tile kernel only): split-K workspace, [total_tiles][8 waves][16 KB] fp32 partials then [total_tiles][8] flags
-struct TnGroup { int n, total_tiles; int splits, tiles_pad; char* ws; unsigned* err; TnProblem pr[TN_MAX_GROUP]; };
+struct TnGroup { int n, total_tiles; int splits, tiles_pad; char* ws; unsigned* err; unsigned* sync; int sync_every, pad_; TnProblem pr[TN_MAX_GROUP]; };
 // fp8 operands (round 3): e5m2 dY x e4m3 X with one dequantisation factor per operand (device scalars).  Two more pointers per
 // problem: 48 problems per launch keep the kernel arguments under 4 KB (GPT-2-medium's 96 block matrices: two launches).
 #define TN_MAX_GROUP8 48
@@ -649,7 +649,7 @@ struct TnProblem8 {
     int lda_b, ldb_b, ldo;
     int P, Q, R, tiles_q, tile_begin;
 };
-struct TnGroup8 { int n, total_tiles; int splits, tiles_pad; char* ws; unsigned* err; TnProblem8 pr[TN_MAX_GROUP8]; };
+struct TnGroup8 { int n, total_tiles; int splits, tiles_pad; char* ws; unsigned* err; unsigned* sync; int sync_every, pad_; TnProblem8 pr[TN_MAX_GROUP8]; };
 template <bool F8> struct TnGroupOf { typedef TnGroup type; };
 template <> struct TnGroupOf<true> { typedef TnGroup8 type; };
 
@@ -945,12 +945,43 @@ __global__ __launch_bounds__(WT ? 512 : 768) void gemm_tn_grouped256_kernel(type
         else if (npre == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // stage 0 published
+        // Pacing experiment (DG_TN_SYNC = n > 0; default off): the workgroups of one XCD that walk the same item sequence meet every
+        // n K steps (one relaxed counter per XCD, class and epoch; bounded wait), so that concurrently running tiles stay at the
+        // same K offset and keep finding each other's operand panels in the XCD's 4 MB L2.  See the measurement in DESIGN section 4.
+        unsigned* sync_ctr = nullptr;
+        unsigned sync_expect = 0;
+        if (gp.sync_every > 0 && gp.sync && lw == 0 && (G & 7) == 0) {
+            const int cls = lo_have ? 1 : 0;
+            int cnt = 0;
+            for (int j = 0; j < (G >> 3); ++j) {
+                const int t2 = (gp.splits == 3) ? q_whole * G + 8 * (j >> 1) + 2 * (lo_x >> 1) + (j & 1) : 0;
+                const bool have = gp.splits == 3 && t2 < gp.total_tiles;
+                if ((have ? 1 : 0) == cls) ++cnt;
+            }
+            sync_expect = (unsigned)cnt;
+            sync_ctr = gp.sync + (lo_x * 2 + cls) * 64;
+        }
         for (int g = 0; g + 1 < total; ++g) {
             int issued = g + TN2_NST; if (issued > total) issued = total;
             if (issued - (g + 2) >= 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // stage g+1 landed, g+2 may fly
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                          // publishes stage g+1; stage g's buffer is free
             if (g + TN2_NST < total) issue();
+            if (sync_ctr && g > 0 && (g % gp.sync_every) == 0 && (g / gp.sync_every) < 64) {
+                unsigned* c = sync_ctr + g / gp.sync_every;
+                if (lane == 0) {
+                    __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int spin = 0; spin < 2000 && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sync_expect; ++spin)
+                        __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
+        if (gp.sync_every > 0 && gp.sync && lw == 0 && lane == 0) {
+            // the workgroup that finishes last zeroes the counters for the next launch
+            const unsigned prev = __hip_atomic_fetch_add(gp.sync + 1024, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == (unsigned)G - 1u) {
+                for (int i = 0; i < 1025; ++i) __hip_atomic_store(gp.sync + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         return;
     }
@@ -1340,6 +1371,7 @@ extern "C" int dg_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb
     return DG_OK;
 }
 
+#define TN_SYNC_BYTES 4128                    // 8 XCDs x 2 classes x 64 epochs of counters + the completion counter (DG_TN_SYNC)
 static int tn_tile_p() {
     static const int v = [] { const char* e = getenv("DG_TN_TILE"); return (e && atoi(e) == 128) ? 128 : 256; }();   // output tile rows
     return v;
@@ -1357,7 +1389,7 @@ extern "C" int64_t dg_gemm_tn_grouped_workspace_bytes(const dg_tn_problem* probl
         const int64_t t = tn_group_tiles(problems + base, n - base < TN_MAX_GROUP ? n - base : TN_MAX_GROUP);
         if (t > most) most = t;
     }
-    return most * (8 * 16384 + 8 * 4) + 16;       // + the sticky error word (last 16 bytes)
+    return most * (8 * 16384 + 8 * 4) + TN_SYNC_BYTES + 16;       // + the pacing counters + the sticky error word (last 16 bytes)
 }
 
 template <typename GroupT, typename ProbT, bool F8, int MAXG>
@@ -1388,6 +1420,12 @@ static int tn_grouped_launch(const dg_tn_problem* problems, int n, void* workspa
         gp.splits = 1;
         gp.ws = nullptr;
         gp.err = workspace ? (unsigned*)((char*)workspace + dg_gemm_tn_grouped_workspace_bytes(problems, n) - 16) : nullptr;
+        {
+            static const int sync_every = [] { const char* e = getenv("DG_TN_SYNC"); return e ? atoi(e) : 0; }();
+            gp.sync_every = (workspace && tile_p == 256) ? sync_every : 0;
+            gp.sync = workspace ? (unsigned*)((char*)workspace + dg_gemm_tn_grouped_workspace_bytes(problems, n) - 16 - TN_SYNC_BYTES) : nullptr;
+            gp.pad_ = 0;
+        }
         const int ncu = dg_num_cus();
         if (tile_p == 256 && workspace && split_mode && nk_min >= 2) {
             // two K halves per tile when that shortens the schedule: rounds x steps per round
