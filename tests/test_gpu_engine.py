@@ -279,6 +279,14 @@ def test_out_of_range_ids_raise_like_torch(dev, golden_dir):
     m.train()
     logits, loss = m(x.to(dev), y.to(dev))                     # the valid batch still runs
     assert torch.isfinite(loss)
+    # the range check is one or two device-to-host syncs per forward that nn.Embedding does not have: a caller that has
+    # validated its data source once can switch it off -- a bad id is then clamped by the kernels, never a fault
+    m.check_ids = False
+    _, loss_bad = m(bad.to(dev), y.to(dev))
+    assert torch.isfinite(loss_bad)
+    m.check_ids = True
+    with pytest.raises(IndexError, match="out of range"):
+        m(bad.to(dev), y.to(dev))
 
 
 def test_train_harness_on_text_and_on_pt_files(dev, golden_dir, tmp_path, capsys):
