@@ -788,3 +788,73 @@ def test_engine_minimal_shapes(dev):
         l0 = eng.step().item()
         l1 = eng.step().item()
         assert l0 > 0 and l1 > 0 and l0 == l0 and l1 == l1
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,p", [(64, 0.0), (4160, 0.2), (16384, 0.2)])
+def test_block_chain_kernel_equals_the_launches_it_replaces(dev, mode, M, p):
+    """dg_block_chain_fwd (round 3): the row-local chain of a residual block -- proj + residual, LayerNorm 2, FFN1 (ReLU, sign
+    bits), FFN2 + residual, the next block's LayerNorm 1 and packed QKV (ref: src/model_component.py:454,505-506,320-325,392-393,
+    404) -- in one persistent launch (modes 0 / 1 / 2) or as the two row-complete GEMMs with a LayerNorm in the epilogue (modes
+    3 / 4), against dg_gemm_nt + dg_layernorm_fwd on the same operands: the GEMM outputs, the dropout masks and the ReLU sign
+    bits are IDENTICAL (same MFMA sequence per element, same hash), the row statistics differ by an fp32 rounding (four 96-column
+    partials combined with Chan's formula instead of one wave-wide sum), hence an occasional bf16 ulp in the LayerNorm outputs
+    and what follows them.  One block (M = 64), several blocks per workgroup (M = 16384 > 256 x 64 is not: 4160 = 65 blocks on
+    256 CUs is), every mode."""
+    ops = _ops()
+    from drakegpt_amd import sublayers as S
+    C = 384
+    assert ops.block_chain_supported(M, C, torch.bfloat16) and not ops.block_chain_supported(M + 8, C, torch.bfloat16)
+    assert not ops.block_chain_supported(M, 768, torch.bfloat16)
+    g = torch.Generator().manual_seed(M + mode)
+    rn = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    bf = torch.bfloat16
+    o = rn(M, C).to(bf).to(dev)
+    x = rn(M, C, sc=2.0).to(dev)
+    f_in = rn(M, 4 * C).clamp_min(0).to(bf).to(dev)
+    W = {k: v.to(bf).to(dev) for k, v in dict(wproj=rn(C, C, sc=C ** -0.5), w1=rn(4 * C, C, sc=C ** -0.5), w2=rn(C, 4 * C, sc=(4 * C) ** -0.5),
+                                           wqkv=rn(3 * C, C, sc=C ** -0.5)).items()}
+    Vv = {k: v.to(dev) for k, v in dict(bproj=rn(C, sc=0.1), b1=rn(4 * C, sc=0.1), b2=rn(C, sc=0.1), ln2w=1 + rn(C, sc=0.1), ln2b=rn(C, sc=0.1),
+                                        ln1w=1 + rn(C, sc=0.1), ln1b=rn(C, sc=0.1)).items()}
+    rng = ops.new_rng_state(99, dev, 5) if p > 0 else None
+    sp, sf = S.site_proj(2), S.site_ffn(2)
+    Wp = {k: ops.pack_chain_weights(v) for k, v in W.items()}
+    # packing is a permutation of 16-byte chunks: same multiset of values, different order
+    assert torch.equal(Wp["w1"].view(-1).float().sort().values, W["w1"].view(-1).float().sort().values) and not torch.equal(Wp["w1"], W["w1"])
+    r = {}
+    if mode in (0, 1, 3):
+        r["x1"] = ops.gemm_nt(o, W["wproj"], torch.float32, bias=Vv["bproj"], dropout_p=p, rng_state=rng, site=sp, residual=x)
+        r["h2"], r["mean2"], r["rstd2"] = ops.layernorm_fwd(r["x1"], Vv["ln2w"], Vv["ln2b"], bf)
+    if mode in (0, 1):
+        r["bits"] = ops.new_sign_bits(M, 4 * C, dev)
+        r["f"] = ops.gemm_nt(r["h2"], W["w1"], bf, bias=Vv["b1"], relu=True, sign_bits_out=r["bits"])
+    if mode in (0, 1, 4):
+        fin, x1in = (f_in, x) if mode == 4 else (r["f"], r["x1"])
+        r["x2"] = ops.gemm_nt(fin, W["w2"], bf if mode == 1 else torch.float32, bias=Vv["b2"], dropout_p=p, rng_state=rng, site=sf, residual=x1in)
+    if mode in (0, 2, 4):
+        r["h1"], r["mean1"], r["rstd1"] = ops.layernorm_fwd(x if mode == 2 else r["x2"], Vv["ln1w"], Vv["ln1b"], bf)
+    if mode in (0, 2):
+        r["qkv"] = ops.gemm_nt(r["h1"], W["wqkv"], bf)
+    if mode == 4:
+        got = ops.block_chain_fwd(4, M, C, f=f_in, x1=x, dropout_p=p, rng_state=rng, site_proj=sp, site_ffn=sf, **Wp, **Vv)
+    else:
+        got = ops.block_chain_fwd(mode, M, C, o=o, x=x, dropout_p=p, rng_state=rng, site_proj=sp, site_ffn=sf, **Wp, **Vv)
+    torch.cuda.synchronize()
+    assert sorted(got) == sorted(r)
+    exact = {"x1"} | ({"x2"} if mode == 4 else set())          # in front of every LayerNorm of the launch: bit for bit
+    for k, ref in r.items():
+        if k == "bits":
+            # bytes of rows beyond M (the second half of a last, half-filled 128-row tile) are never written by either side
+            idx = torch.arange(ref.numel(), device=dev)
+            row = (idx // 3072 // 8) * 128 + ((idx // 384) % 8 >> 1) * 32 + ((idx // 64) % 2) * 16 + (idx % 16)
+            ok = row < M
+            assert int((got[k][ok] != ref[ok]).sum()) <= max(2, ref.numel() // 100000), k      # a bf16 ulp of h2 can move a pre-activation across zero
+        elif k in exact:
+            assert torch.equal(got[k], ref), k
+        else:
+            e = rel(got[k].float(), ref.float())
+            # (mode 0: the second LayerNorm's input already carries the first one's bf16-ulp differences through FFN1 / FFN2)
+            stat_tol = 1e-4 if (mode == 0 and k in ("mean1", "rstd1")) else 2e-6
+            assert e < (stat_tol if k.startswith(("mean", "rstd")) else 3e-4), (k, e)
+    with pytest.raises(RuntimeError):                          # operands are validated before the launch
+        ops.block_chain_fwd(3, M, C, o=o, x=x[: M - 1], wproj=Wp["wproj"], bproj=Vv["bproj"], ln2w=Vv["ln2w"], ln2b=Vv["ln2b"])
