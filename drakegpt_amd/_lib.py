@@ -122,6 +122,7 @@ SIGNATURES = {
     "dg_adamw_step": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f, _vp, _i, _vp],
     "dg_block_chain_supported": [_i, _i],
     "dg_block_chain_fwd": [C.POINTER(BlockChainArgs), _vp],
+    "dg_l2_warm": [_vp, _i64, _vp],
     "dg_pack_chain_weights": [_vp, _i64, _vp, _i, _i, _vp],
     "dg_pack_chain_weights_batched": [_vp, _i, _i, _vp],
 }

@@ -64,7 +64,7 @@ struct ChainP {
     float eps;
     const uint32_t* rng; uint32_t site_proj, site_ffn, thr; float inv_keep; int drop;
     int stagger;                         // experiment (DG_CHAIN_STAGGER): workgroup group g = (blockIdx / 8) % 4 starts g * stagger * 64 cycles late
-    int dbg;                             // timing ablations (DG_CHAIN_DBG, results are wrong on purpose): 1 = every stage re-reads K step 0, 2 = no MFMA, 3 = no DMA after the prologue, 4 = no epilogues, 5 = 4 + idle loaders, 6 = no epilogue stores, 7 = no residual loads
+    int dbg;                             // timing ablations (DG_CHAIN_DBG, results are wrong on purpose): 1 = every stage re-reads K step 0, 2 = no MFMA, 3 = no DMA after the prologue, 4 = no epilogues, 5 = 4 + idle loaders, 6 = no epilogue stores, 7 = no residual loads, 11 = no L2 warm-up of the weight stream
 };
 
 __device__ __forceinline__ void ch_wait_vm(int n) {          // counted wait on the loaders' LDS-DMA pieces (n is wave-uniform)
@@ -233,6 +233,11 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
     uint32_t key_proj = 0, key_ffn = 0;
     if (p.drop) { key_proj = dg_site_key_dev(p.rng, p.site_proj); key_ffn = dg_site_key_dev(p.rng, p.site_ffn); }
     const int col_l = wn * 96 + (fg & 1) * 16 + (fg >> 1) * 8;            // + 32 q: first of the lane's 8 consecutive columns
+    // Every epilogue derives its row / column offsets from an OPAQUE copy of the lane id: left to itself the compiler hoists the ~40
+    // per-lane 64-bit addresses of all nine epilogues to the top of the block, keeps them alive across every K loop and spills them
+    // (97 registers in mode 0: 76 MB of scratch written by the launch's 196608 threads before the first MFMA, as much read back --
+    // the PMC pass showed 431 MB moved for 280 MB of operands).
+    auto opaque_lane = [&]() -> int { int l = lane; asm volatile("" : "+v"(l)); return l; };
 
     // accumulators of (i, q) -> the lane's 8 consecutive columns of row i*16 + fr (see gemm_nt_ws_kernel's epilogue)
     auto take = [&](int i, int q, float (&v)[8]) {
@@ -266,6 +271,7 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
     // (Chan's formula: exact), then y = (x - mean) rstd gamma + beta as bf16 to global memory and into the resident A image.
     auto layernorm = [&](float (&xv)[2][3][8], float* scratch, int64_t row0, const float* gamma, const float* beta, float* mean_o,
                          float* rstd_o, bf16_t* y) {
+        const int lo = opaque_lane(), fr = lo & 15, fg = lo >> 4, col_l = wn * 96 + (fg & 1) * 16 + (fg >> 1) * 8;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float s = 0.f;
@@ -320,6 +326,7 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
     };
     // bias + dropout + residual epilogue of proj / FFN2 -> xv (and the fp32 / bf16 stream in global memory)
     auto residual_epilogue = [&](float (&xv)[2][3][8], int64_t row0, const float* bias, const float* res, uint32_t key, float* out32, bf16_t* out16) {
+        const int lo = opaque_lane(), fr = lo & 15, fg = lo >> 4, col_l = wn * 96 + (fg & 1) * 16 + (fg >> 1) * 8;
         f32x4 bq[2][2], r[2][2][2];                                       // [q & 1]: block q + 1 is requested before block q is computed
         auto request = [&](int q) {
             const int col = col_l + 32 * q;
@@ -363,6 +370,28 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
         }
     };
 
+    // L2 WARM-UP OF THE WEIGHT STREAM.  Inside the training step the packed weights were written a millisecond ago (optimizer step)
+    // and are cold when this launch starts; all 32 workgroups of an XCD then miss on the SAME lines in lockstep, stage after stage,
+    // and the pipeline's lead of three K steps (~1.5 us) does not cover an HBM miss: measured inside the captured step,
+    // block_chain_fwd_kernel<0> took 120.8 us against 107 us back to back -- and 91.0 us once every line had been touched
+    // beforehand (a separate launch at first: 6.8 us; the step went 2.513 -> 2.397 ms).  The MFMA waves have nothing to do until
+    // the first barrier: each of them touches its share of the stream's 128-byte lines (workgroup j of the XCD: lines j + 32 k), all
+    // requests in flight at once; the values are discarded, the registers retired by the first piece's vmcnt(0).
+    if (p.dbg != 11) {
+        const int jx = (int)blockIdx.x >> 3, per = ((int)gridDim.x >> 3) ? ((int)gridDim.x >> 3) : 1;
+        float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;                    // one touch per matrix and lane (a full grid covers every line)
+        auto warm = [&](float& dst, const char* base, int n_stages) {
+            const int i = jx + per * tid;
+            if (i < n_stages * (CH_STAGE_B / 128)) asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(base + (int64_t)i * 128) : "memory");
+        };
+        if (HAS_PROJ) warm(w0, p.wproj, KS);
+        if (HAS_FFN1) warm(w1, p.w1, 4 * KS);
+        if (HAS_FFN2) warm(w2, p.w2, 4 * KS);
+        if (HAS_QKV) warm(w3, p.wqkv, 3 * KS);
+        // the destination registers stay reserved until the touches have returned (the compiler knows nothing of loads in flight);
+        // these waves would otherwise sit at the first barrier for as long
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) :: "memory");
+    }
     u32x4 fa0[2], fb0[6], fa1[2], fb1[6];
     for (int blk = blockIdx.x; blk < p.n_blocks; blk += gridDim.x) {
         const int64_t row0 = (int64_t)blk * CH_ROWS;
@@ -382,8 +411,6 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
             layernorm(xv, (float*)(lds + 0 * CH_STAGE + CH_STAGE_B), row0, p.ln1w, p.ln1b, p.mean1, p.rstd1, p.h1);
         }
         __builtin_amdgcn_s_barrier();                                     // P
-        read_B(fb0, 0);
-        read_A_res(fa0, 0);
         // one GEMM piece = NSTEP K steps entering with (fa0, fb0) loaded for its first step; `ring_a`: A operand from the ring.
         // After the piece's last MFMA the caller runs the epilogue; `next`: 0 = nothing follows in this block, 1 = prefetch B and A
         // of the following piece's first step, 2 = B only (its A operand is written by this piece's epilogue: read it behind the
@@ -398,7 +425,16 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto piece = [&](int nstep, bool ring_a, int next, bool next_ring_a, bool deferred, bool drain = false) {
+        // One GEMM piece = nstep K steps.  It starts with NO fragments loaded: nothing is held across the epilogue in front of it (24
+        // registers of prefetched weight fragments across an epilogue that keeps 48 row values, their operands and gamma / beta alive
+        // were most of mode 0's spills; each piece instead exposes one LDS read latency at its start, ~0.15 us).  The first stage's
+        // weight fragments are read in FRONT of the piece's first barrier (stage g was published by the barrier before and is refilled
+        // behind this one); its A fragments there too, unless the epilogue in front has just written the resident image
+        // (`a_after_barrier`: the LayerNorm pieces) -- those are read behind the barrier.  `next`: a piece follows in this block
+        // (its first stage is published by this piece's last barrier).
+        auto piece = [&](int nstep, bool ring_a, bool next, bool a_after_barrier, bool drain = false) {
+            read_B(fb0, g);
+            if (!a_after_barrier) { if (ring_a) read_A_ring(fa0, g); else read_A_res(fa0, 0); }
             for (int t = 0; t < nstep; t += 2) {
                 if (drain && t == nstep - 2 && p.dbg != 10) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 // the previous epilogue's stores are acknowledged before the loaders can ask for them again (FFN2's A operand: the
@@ -406,7 +442,7 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
                 // t == 2 this wait serialised every epilogue's store burst with the next piece's first K steps
                 if (t == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 pipe_barrier();                                           // publishes stage g+1
-                if (t == 0 && deferred) read_A_res(fa0, 0);
+                if (t == 0 && a_after_barrier) read_A_res(fa0, 0);
                 read_B(fb1, g + 1);
                 if (ring_a) read_A_ring(fa1, g + 1); else read_A_res(fa1, t + 1);
                 mma(fa0, fb0);
@@ -417,8 +453,6 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
                     if (ring_a) read_A_ring(fa0, g + 1); else read_A_res(fa0, t + 2);
                 } else if (next) {
                     pipe_barrier();
-                    read_B(fb0, g + 1);
-                    if (next == 1) { if (next_ring_a) read_A_ring(fa0, g + 1); else read_A_res(fa0, 0); }
                 }
                 mma(fa1, fb1);
                 ++g;
@@ -433,7 +467,7 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
         };
         if (HAS_PROJ) {
             // ---- proj + residual + LayerNorm 2
-            piece(KS, false, HAS_FFN1 ? 2 : 0, false, false, true);
+            piece(KS, false, HAS_FFN1, false, true);
             if (p.dbg == 4 || p.dbg == 5) __builtin_amdgcn_s_barrier();
             else {
                 float xv[2][3][8];
@@ -444,8 +478,10 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
         if (HAS_FFN1) {
             // ---- FFN1: four column chunks of the hidden layer, bias + ReLU + sign bits
             for (int c = 0; c < 4; ++c) {
-                piece(KS, false, 1, c == 3, c == 0);
+                piece(KS, false, true, c == 0);
                 if (p.dbg == 4 || p.dbg == 5) continue;
+                const int lo = opaque_lane(), fr = lo & 15, fg = lo >> 4, col_l = wn * 96 + (fg & 1) * 16 + (fg >> 1) * 8;
+                const int lane = lo;
                 const int tile_lo = (blk >> 1) * (4 * C / 192) + c * 2 + (wn >> 1);
                 const int wv = (((blk & 1) * 2 + wm) * 2 + (wn & 1));
                 f32x4 bq[3][2];                                           // every bias load in front of the first store
@@ -480,7 +516,7 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
         }
         if (HAS_FFN2) {
             // ---- FFN2 + residual (+ LayerNorm 1 of the next block)
-            piece(4 * KS, MODE != 4, HAS_QKV ? 2 : 0, false, false, true);
+            piece(4 * KS, MODE != 4, HAS_QKV, false, true);
             if (p.dbg == 4 || p.dbg == 5) { if (LN_FFN2) __builtin_amdgcn_s_barrier(); }
             else {
                 float xv[2][3][8];
@@ -492,8 +528,9 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
         if (HAS_QKV) {
             // ---- the next block's packed q / k / v: three column chunks, plain bf16 stores
             for (int c = 0; c < 3; ++c) {
-                piece(KS, false, c < 2 ? 1 : 0, false, MODE == 0 && c == 0);
+                piece(KS, false, c < 2, MODE == 0 && c == 0);
                 if (p.dbg == 4 || p.dbg == 5) continue;
+                const int lo = opaque_lane(), fr = lo & 15, fg = lo >> 4, col_l = wn * 96 + (fg & 1) * 16 + (fg >> 1) * 8;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int col = c * C + col_l + 32 * q;
@@ -555,6 +592,24 @@ extern "C" int dg_pack_chain_weights_batched(const int64_t* desc, int n_desc, in
     if (!desc || n_desc <= 0 || total_stages <= 0) return DG_ERR_ARG;
     PackOne one{nullptr, nullptr, 0, 0, 0};
     hipLaunchKernelGGL(pack_chain_kernel, dim3(total_stages), dim3(256), 0, (hipStream_t)stream, desc, n_desc, one);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
+// L2 warm-up for a weight stream: inside the training step the packed weights of a layer were written a millisecond ago and are cold
+// by the time its chain launch runs; the chain kernel's 32 workgroups per XCD then all wait on the same missing lines, stage after
+// stage (its prefetch lead is 3 K steps = ~1.5 us).  Every XCD touches every 128-byte line once (workgroup b: XCD b & 7, lines
+// (b >> 3) + 32 k), so that the stream is an L2 hit for all of them.
+__global__ __launch_bounds__(256) void l2_warm_kernel(const char* __restrict__ p, int64_t n_lines, float* __restrict__ sink) {
+    const int j = (int)blockIdx.x >> 3, per = (int)gridDim.x >> 3;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)j * 256 + threadIdx.x; i < n_lines; i += (int64_t)per * 256) acc += *(const float*)(p + i * 128);
+    if (acc == 123.456f && sink) sink[0] = acc;            // (never true for weights that matter: keeps the loads alive)
+}
+
+extern "C" int dg_l2_warm(const void* p, int64_t bytes, void* stream) {
+    if (!p || bytes <= 0 || (((uintptr_t)p) & 127)) return DG_ERR_ARG;
+    hipLaunchKernelGGL(l2_warm_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, (const char*)p, bytes / 128, (float*)nullptr);
     DG_LAUNCH_CHECK();
     return DG_OK;
 }

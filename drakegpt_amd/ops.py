@@ -635,6 +635,12 @@ def block_chain_supported(M: int, C: int, dtype: torch.dtype) -> bool:
     return dtype == torch.bfloat16 and bool(lib.dg_block_chain_supported(int(M), int(C)))
 
 
+def l2_warm(t: Tensor) -> None:
+    """touch every 128-byte line of the contiguous tensor t from every XCD (its storage must start on a 128-byte boundary)"""
+    _chk(t, "t")
+    check(lib.dg_l2_warm(_p(t), t.numel() * t.element_size(), _stream()), "dg_l2_warm")
+
+
 def pack_chain_weights(W: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """W [N, K] bf16 (N % 384 == 0, K % 32 == 0) -> the packed operand dg_block_chain_fwd streams (same shape / byte count)"""
     _chk(W, "W", torch.bfloat16, contiguous=False)

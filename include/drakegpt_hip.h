@@ -388,6 +388,9 @@ int dg_block_chain_fwd(const dg_block_chain_args* args, void* stream);
 /* w [N, K] bf16 row-major with leading dimension ld (N % 384 == 0, K % 32 == 0) -> packed (N * K elements).  Batched form: a
  * device table of n_desc rows {src, dst, N, K, first stage of the matrix (prefix sum of N / 384 * K / 32), ld} (int64 each):
  * every weight matrix of a model in one launch of total_stages workgroups. */
+/* touch every 128-byte line of [p, p + bytes) once from every XCD (p 128-byte aligned): an L2 warm-up for a weight stream that the
+ * next launch reads from all workgroups in lockstep */
+int dg_l2_warm(const void* p, int64_t bytes, void* stream);
 int dg_pack_chain_weights(const void* w, int64_t ld, void* packed, int N, int K, void* stream);
 int dg_pack_chain_weights_batched(const int64_t* desc, int n_desc, int total_stages, void* stream);
 

@@ -376,11 +376,13 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
+@pytest.mark.parametrize("switch", ["DG_CHAIN_LN", "DG_CHAIN"])
 @pytest.mark.parametrize("p", [0.0, 0.2])
-def test_layernorm_inside_gemm_epilogue_equals_separate_launches(dev, p):
+def test_layernorm_inside_gemm_epilogue_equals_separate_launches(dev, p, switch):
     """round 3: proj + residual + LayerNorm 2 and FFN2 + residual + the next block's LayerNorm 1 as row-complete GEMMs whose
     epilogue runs the LayerNorm (dg_block_chain_fwd modes 3 / 4, ref: src/model_component.py:454,505-506,320-325) against the
-    same engine with the separate dg_gemm_nt + dg_layernorm_fwd launches (DG_CHAIN_LN=0): same GEMM arithmetic and dropout masks,
+    same engine with the separate dg_gemm_nt + dg_layernorm_fwd launches (DG_CHAIN_LN=0), and the WHOLE row-local chain between two
+    attention calls as one launch per layer (DG_CHAIN=1: modes 2 / 0 / 1) against the same: same GEMM arithmetic and dropout masks,
     row statistics combined from four 96-column partials instead of one wave-wide sum -- differences at fp32 rounding level in
     mean / rstd, an occasional bf16 ulp in the normalised activations.  Also the packed-weight refresh after the optimizer step
     (second step: Adam's first update is lr * sign(g), so gradients that differ in the last bit near zero move weights apart by
@@ -393,14 +395,19 @@ def test_layernorm_inside_gemm_epilogue_equals_separate_launches(dev, p):
     ys = [torch.randint(0, V, (B, T), generator=g).to(dev) for _ in range(2)]
     out = {}
     for mode in ("1", "0"):
-        os.environ["DG_CHAIN_LN"] = mode
+        os.environ[switch] = mode
+        if switch == "DG_CHAIN_LN":
+            os.environ["DG_CHAIN"] = "0"                # (the one-launch chain is the default: off for this comparison)
         try:
             torch.manual_seed(42)
             m = D.TransformerLM(V, C, T, NH, L, p, precision="bf16").to(dev).train()
             eng = TrainEngine(m, B, T, lr=1e-3, seed=11, use_graph=True)
         finally:
-            os.environ.pop("DG_CHAIN_LN", None)
-        assert eng.chain_ln == (mode == "1")
+            os.environ.pop(switch, None)
+            os.environ.pop("DG_CHAIN", None)
+        assert (eng.chain_ln if switch == "DG_CHAIN_LN" else eng.chain_full) == (mode == "1")
+        if switch == "DG_CHAIN_LN":
+            assert not eng.chain_full
         eng.keep_logits = True
         res = []
         for x, y in zip(xs, ys):
