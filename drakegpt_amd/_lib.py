@@ -18,7 +18,7 @@ DG_F32 = 0
 DG_BF16 = 1
 DG_FP8_E4M3 = 2
 DG_FP8_E5M2 = 3
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class GemmNtArgs(C.Structure):
@@ -64,6 +64,24 @@ class BlockChainArgs(C.Structure):
         ("ln1w", C.c_void_p), ("ln1b", C.c_void_p), ("mean1", C.c_void_p), ("rstd1", C.c_void_p), ("h1", C.c_void_p),
         ("wqkv", C.c_void_p), ("qkv", C.c_void_p),
         ("dropout_p", C.c_float), ("rng_state", C.c_void_p), ("site_proj", C.c_uint32), ("site_ffn", C.c_uint32),
+    ]
+
+
+class BlockChainBwdArgs(C.Structure):
+    """struct dg_block_chain_bwd_args"""
+    _fields_ = [
+        ("mode", C.c_int32), ("M", C.c_int32), ("C", C.c_int32), ("reserved", C.c_int32),
+        ("dqkv", C.c_void_p), ("wqkvT", C.c_void_p), ("x", C.c_void_p), ("mean1", C.c_void_p), ("rstd1", C.c_void_p), ("ln1w", C.c_void_p),
+        ("dresid1", C.c_void_p), ("dx1", C.c_void_p), ("g1", C.c_void_p),
+        ("dln1w_part", C.c_void_p), ("dln1b_part", C.c_void_p), ("gbias1_part", C.c_void_p),
+        ("g_in", C.c_void_p),
+        ("w2T", C.c_void_p), ("sign_bits", C.c_void_p), ("sign_bits_bytes", C.c_int64), ("df", C.c_void_p), ("db1_part", C.c_void_p),
+        ("w1T", C.c_void_p), ("x1", C.c_void_p), ("mean2", C.c_void_p), ("rstd2", C.c_void_p), ("ln2w", C.c_void_p),
+        ("dresid2", C.c_void_p), ("dx2", C.c_void_p), ("g2", C.c_void_p),
+        ("dln2w_part", C.c_void_p), ("dln2b_part", C.c_void_p), ("gbias2_part", C.c_void_p),
+        ("wprojT", C.c_void_p), ("dout", C.c_void_p),
+        ("part_stride", C.c_int64),
+        ("dropout_p", C.c_float), ("rng_state", C.c_void_p), ("site_ffn_below", C.c_uint32), ("site_proj", C.c_uint32),
     ]
 
 
@@ -125,6 +143,8 @@ SIGNATURES = {
     "dg_l2_warm": [_vp, _i64, _vp],
     "dg_pack_chain_weights": [_vp, _i64, _vp, _i, _i, _vp],
     "dg_pack_chain_weights_batched": [_vp, _i, _i, _vp],
+    "dg_block_chain_bwd_supported": [_i, _i],
+    "dg_block_chain_bwd": [C.POINTER(BlockChainBwdArgs), _vp],
 }
 
 

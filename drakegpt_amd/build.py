@@ -34,6 +34,7 @@ SOURCES = [
     "attention_mfma.hip",
     "cross_entropy.hip",
     "chain.hip",
+    "chain_bwd.hip",
 ]
 
 

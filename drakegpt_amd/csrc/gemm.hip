@@ -318,6 +318,10 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
     p.mask_vec_ok = a->relu_mask && (a->ldmask % 4 == 0) && ((((uintptr_t)a->relu_mask) % (4 * esz)) == 0);
     { static const int dbg = [] { const char* e = getenv("DG_GEMM_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
     { static const int rpf = [] { const char* e = getenv("DG_NT_RESPF"); return e ? atoi(e) : 0; }(); p.res_prefetch = rpf; }
+    {   // weights of at most 2 MB (every block Linear of the scaled model; not lm_head at the GPT-2 vocabulary), one touch per lane
+        static const int wm = [] { const char* e = getenv("DG_NT_WARM"); return e ? atoi(e) : 1; }();     // same box, headline step: 2.498 -> 2.478 ms
+        p.warm_b = (wm && (int64_t)a->N * a->ldb * esz <= (2 << 20) && (a->ldb * esz) % 128 == 0 && (((uintptr_t)a->B) & 127) == 0) ? 1 : 0;
+    }
     p.stamps = g_stamp_buffer;
     const int tiles_m = (a->M + BM - 1) / BM;
     p.tiles_n = (a->N + BN - 1) / BN;

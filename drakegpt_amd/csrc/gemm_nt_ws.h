@@ -57,6 +57,7 @@ struct NtParams {
     unsigned long long* stamps;   // diagnostic build aid: per-workgroup s_memtime stamps (NULL in production)
     int dbg;      // ablation only (DG_GEMM_DBG): 1 = no operand loads after the first stage, 2 = no LDS reads / MFMA, 3 = no stores, 4 = 1 + 3
     const float* scale_a; const float* scale_b;   // fp8 operands: per-tensor dequantisation factors (device scalars), acc *= sa * sb
+    int warm_b;                   // touch the B operand's lines from the idle MFMA waves before the first barrier (weights cold inside the step)
     int res_prefetch;             // EPI 3 / 7: loader waves touch the residual tile ahead of the epilogue (DG_NT_RESPF, default 0: measured slower)
     // EPI 8: the output is ALSO written as e4m3 (the next GEMM's fp8 operand) with delayed per-tensor scaling
     unsigned char* q8; int64_t ldq8;          // [M][ldq8] bytes
@@ -589,6 +590,17 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     };
     stamp();
     // ---- MFMA role
+    // L2 warm-up of the weight operand (round 3; p.warm_b, DG_NT_WARM): inside the training step B -- a bf16 shadow or W^T the
+    // optimizer step rewrote a millisecond ago -- is cold, and the tiles of an XCD all miss on its lines.  These waves idle until
+    // the first barrier: each touches one 128-byte line of B (workgroup j of the XCD: lines j + 32 k), all requests in flight at once.
+    if (p.warm_b) {
+        const int jx = (int)blockIdx.x >> 3, per = ((int)gridDim.x >> 3) ? ((int)gridDim.x >> 3) : 1;
+        const int64_t n_lines = ((int64_t)p.N * p.ldb_b) >> 7;
+        const int64_t i = jx + (int64_t)per * tid;
+        float wv = 0.f;
+        if (i < n_lines) asm volatile("global_load_dword %0, %1, off" : "=v"(wv) : "v"(p.B + i * 128) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(wv) :: "memory");
+    }
     u32x4 fa0[2], fb0[NJ], fa1[2], fb1[NJ];
     __builtin_amdgcn_s_barrier();                                  // stage 0 published by the loaders
     read_frags(fa0, fb0, lds, 0);

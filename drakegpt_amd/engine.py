@@ -69,6 +69,7 @@ class ShadowWeights:
         self.fwd8_map: Dict[int, Tuple[Tensor, Tensor]] = {}      # fp8 mode: (e4m3 copy, dequantisation scale [1])
         self.bwd8_map: Dict[int, Tuple[Tensor, Tensor]] = {}
         self.pack_map: Dict[int, Tensor] = {}                      # proj / second FFN Linear in dg_block_chain_fwd's streaming order
+        self.packT_map: Dict[int, Tensor] = {}                     # the W^T operands in dg_block_chain_bwd's streaming order
 
     def fwd(self, W: Tensor) -> Tensor:
         return self.fwd_map[W.data_ptr()]
@@ -81,6 +82,9 @@ class ShadowWeights:
 
     def pack(self, W: Tensor) -> Optional[Tensor]:
         return self.pack_map.get(W.data_ptr())
+
+    def packT(self, W: Tensor) -> Optional[Tensor]:
+        return self.packT_map.get(W.data_ptr())
 
     def bwd8(self, W: Tensor):
         return self.bwd8_map[W.data_ptr()]
@@ -238,10 +242,18 @@ class TrainEngine:
         self.chain_full = (_os.environ.get("DG_CHAIN", "1") != "0" and not self.fp8 and self.NH * self.H == self.C and self.last_block_act
                            and ops.block_chain_supported(self.M, self.C, self.act))
         self.chain_warm = _os.environ.get("DG_CHAIN_WARM", "0") == "1"
+        # The same for the backward pass (dg_block_chain_bwd: dX-QKV + LayerNorm-1 backward of block l, dX-FFN2 / dX-FFN1 / LayerNorm-2
+        # backward / dX-proj of block l - 1 in one launch; backward launches per block 8 -> 3).  Needs the bf16 gradient stream and one
+        # gradient exchange (a chain straddles two blocks: no layer-group seams).  Opt-in (DG_CHAIN_BWD=1) until it beats the separate launches
+        # inside the step (first measurement: 136 vs 128.5 us per layer).
+        self.chain_bwd = (_os.environ.get("DG_CHAIN_BWD", "0") == "1" and self.chain_full and self.stream_dtype == torch.bfloat16
+                          and ops.block_chain_bwd_supported(self.M, self.C, self.act))
         self.chain_ln = (_os.environ.get("DG_CHAIN_LN", "0") == "1" and not self.fp8 and self.NH * self.H == self.C
                          and ops.block_chain_supported(self.M, self.C, self.act))
         self._build_layout()
         self.dp_buckets = self._choose_buckets(self._dp_buckets_arg)
+        if self.dp_buckets > 1:
+            self.chain_bwd = False
         self._alloc_and_adopt()
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay], dtype=torch.float32, device=self.dev)
         # dropout stream differs per data-parallel rank; the step word also drives Adam's bias correction
@@ -397,6 +409,8 @@ class TrainEngine:
         # partial rows of the bias / LayerNorm gradients: G row chunks, or as many as the GEMM epilogue that emits the column
         # sums (FeedForward's first bias) asks for; rows a producer never writes stay zero
         self.Gv = max(self.G, ops.gemm_nt_colsum_rows(self.act, self.M, 4 * self.C, self.C))
+        if self.chain_bwd:
+            self.Gv = max(self.Gv, 2 * (self.M // 64))            # dg_block_chain_bwd: two partial rows per 64-row block
         self.vparts = torch.zeros((self.Gv, self.layB.size), dtype=torch.float32, device=dev)
         NH, H = self.NH, self.H
 
@@ -449,7 +463,9 @@ class TrainEngine:
             self.wscale_f = torch.ones(n_fp8, dtype=torch.float32, device=dev)
             self.wscale_b = torch.ones(n_fp8, dtype=torch.float32, device=dev)
         self.wpack_flat = torch.zeros(self.layA.size, dtype=torch.bfloat16, device=dev) if (self.chain_ln or self.chain_full) else None
+        self.wtpack_flat = torch.zeros(self.layA.size, dtype=torch.bfloat16, device=dev) if self.chain_bwd else None
         self._pack_pairs = []
+        self._packT_pairs = []
         for key, (off, shape) in self.layA.entries.items():
             W = self.param_view(key)
             n = shape[0] * shape[1]
@@ -465,6 +481,10 @@ class TrainEngine:
             Wt = self.wt_flat[wt_off:wt_off + wt_sizes[key]].view(wt_shape)
             self.weights.bwd_map[W.data_ptr()] = Wt
             self._mats.append((W, Wt))
+            if self.chain_bwd and key != "lm.w":
+                pkT = self.wtpack_flat[off:off + n].view(wt_shape)
+                self.weights.packT_map[W.data_ptr()] = pkT
+                self._packT_pairs.append((Wt, pkT))
             if self.fp8 and (key != "lm.w" or self.fp8_head):
                 i = len(seg_f)
                 seg_f.append([off, n])
@@ -493,7 +513,7 @@ class TrainEngine:
         ops.transpose_cast_batched(*self._tr_table, self.act, in_dtype=torch.bfloat16 if from_shadow else torch.float32)
         if self._pack_pairs:
             if getattr(self, "_pack_table", None) is None:
-                self._pack_table = ops.make_pack_table(self._pack_pairs, self.dev)
+                self._pack_table = ops.make_pack_table(self._pack_pairs + self._packT_pairs, self.dev)
             ops.pack_chain_weights_batched(*self._pack_table)
         if self.fp8:
             # e4m3 copies of every block matrix and of every W^T, per-matrix scales: two launch pairs for the whole model
@@ -657,6 +677,62 @@ class TrainEngine:
                 dh = S.attn_bwd(run, sa, dh, P["ln1w"], P["wqkv"], P["wproj"], True, B, T, self.NH, self.H, p, p, l, sink, keys, g_in=g_next)
         st["dh"], st["g_next"] = dh, g_next
 
+    def _backward_layers_chain(self, st: dict) -> None:
+        """backward of all residual blocks with everything between two attention-backward calls in ONE launch (dg_block_chain_bwd):
+        the top block's second half (mode 1), per block boundary the first half of block l + the second half of block l - 1 (mode 0),
+        block 0's first half (mode 2).  Records the same (dY, X) operand pairs for the grouped dW launch and writes the same partial
+        rows of the bias / LayerNorm gradients (two per 64-row block) as the separate launches."""
+        run, sink, saved, x_idx = st["run"], st["sink"], st["saved"], st["x_idx"]
+        B, T = x_idx.shape
+        M, C, L = self.M, self.C, self.L
+        p = run.p(self.p_drop)
+        pkT = self.weights.packT
+        stride = self.layB.size
+
+        def vec(key, n):
+            return sink.vector(key, n)[0]
+
+        def second(l):
+            P = self._layer_params(l)
+            x1, h2, mean2, rstd2, f, bits = saved[l][1]
+            return dict(w2T=pkT(P["w2"]), bits=bits, db1_part=vec(f"{l}.b1", 4 * C), w1T=pkT(P["w1"]), x1=x1, mean2=mean2, rstd2=rstd2,
+                        ln2w=P["ln2w"], dln2w_part=vec(f"{l}.ln2w", C), dln2b_part=vec(f"{l}.ln2b", C), gbias2_part=vec(f"{l}.bproj", C),
+                        wprojT=pkT(P["wproj"]), site_proj=S.site_proj(l))
+
+        def first(l, dqkv, dresid):
+            P = self._layer_params(l)
+            x, h1, m1, r1, qkv, o, lse = saved[l][0]
+            return dict(dqkv=dqkv, wqkvT=pkT(P["wqkv"]), x=x, mean1=m1, rstd1=r1, ln1w=P["ln1w"], dresid1=dresid,
+                        dln1w_part=vec(f"{l}.ln1w", C), dln1b_part=vec(f"{l}.ln1b", C),
+                        gbias1_part=vec(f"{l - 1}.b2", C) if l > 0 else None, site_ffn_below=S.site_ffn(l - 1) if l > 0 else 0)
+
+        def weights_and_attention(l, g, r):
+            """the four weight-gradient problems of block l and its attention backward; returns dqkv"""
+            x, h1, m1, r1, qkv, o, lse = saved[l][0]
+            x1, h2, mean2, rstd2, f, bits = saved[l][1]
+            S.weight_grad(sink, f"{l}.w2", g, f, C, 4 * C)
+            S.weight_grad(sink, f"{l}.w1", r["df"], h2, 4 * C, C)
+            S.weight_grad(sink, f"{l}.wproj", r["g2"], o, C, C)
+            dqkv = ops.attn_bwd(qkv, o, r["dout"], lse, B, T, self.NH, self.H, self.H ** -0.5, p, run.rng, S.site_attn(l))
+            S.weight_grad(sink, f"{l}.wqkv", dqkv, h1, 3 * C, C)
+            return dqkv
+
+        kw = dict(part_stride=stride, dropout_p=p, rng_state=run.rng)
+        dh = st["dh"]
+        l = L - 1
+        part, pstride, n = sink.vector(f"{l}.b2", C)
+        g = ops.dropout_bwd_cast(dh, run.act, p, run.rng, S.site_ffn(l), colsum_part=part, part_stride=pstride, n_partials=n)
+        r = ops.block_chain_bwd(1, M, C, g_in=g, dresid2=dh, **second(l), **kw)
+        while True:
+            dqkv = weights_and_attention(l, g, r)
+            if l == 0:
+                break
+            r = ops.block_chain_bwd(0, M, C, **first(l, dqkv, r["dx2"]), **second(l - 1), **kw)
+            g = r["g1"]
+            l -= 1
+        r = ops.block_chain_bwd(2, M, C, **first(0, dqkv, r["dx2"]), **kw)
+        st["dh"], st["g0"], st["g_next"] = r["dx1"], r["g1"], None
+
     def _backward_end(self, st: dict, group: int = 0) -> None:
         x_idx, dh, sink = st["x_idx"], st["dh"], st["sink"]
         B, T = x_idx.shape
@@ -673,7 +749,10 @@ class TrainEngine:
 
     def _backward(self, run: S.Run, x_idx: Tensor, ctx):
         st = self._backward_begin(run, x_idx, ctx)
-        self._backward_layers(st, reversed(range(self.L)))
+        if self.chain_bwd and x_idx.numel() == self.M:
+            self._backward_layers_chain(st)
+        else:
+            self._backward_layers(st, reversed(range(self.L)))
         self._backward_end(st)
 
     def _train_run(self) -> S.Run:

@@ -729,3 +729,68 @@ def block_chain_fwd(mode: int, M: int, Cd: int, *, o: Optional[Tensor] = None, x
     a.site_proj, a.site_ffn = site_proj, site_ffn
     check(lib.dg_block_chain_fwd(C.byref(a), _stream()), "dg_block_chain_fwd")
     return out
+
+
+def block_chain_bwd_supported(M: int, C: int, dtype: torch.dtype) -> bool:
+    """can dg_block_chain_bwd run this shape?  (bf16 operands and gradient stream, C = 384, M % 64 == 0, M / 64 <= #CUs)"""
+    return dtype == torch.bfloat16 and bool(lib.dg_block_chain_bwd_supported(int(M), int(C)))
+
+
+def block_chain_bwd(mode: int, M: int, Cd: int, *, part_stride: int, dqkv=None, wqkvT=None, x=None, mean1=None, rstd1=None, ln1w=None, dresid1=None,
+                    dln1w_part=None, dln1b_part=None, gbias1_part=None, g_in=None, w2T=None, bits=None, db1_part=None, w1T=None, x1=None,
+                    mean2=None, rstd2=None, ln2w=None, dresid2=None, dln2w_part=None, dln2b_part=None, gbias2_part=None, wprojT=None,
+                    dropout_p: float = 0.0, rng_state: Optional[Tensor] = None, site_ffn_below: int = 0, site_proj: int = 0) -> dict:
+    """the backward pass's row-local chain between two attention-backward calls in one launch (dg_block_chain_bwd).
+    mode 0: dX-QKV + LayerNorm-1 backward of block l, then dX-FFN2 / dX-FFN1 / LayerNorm-2 backward / dX-proj of block l - 1;
+    1: the second half only (g_in = the operand of dX-FFN2); 2: the first half only.  Weights are the PACKED W^T operands
+    (pack_chain_weights of the [in, out] shadows).  The *_part arguments are views of row 0 of a partial buffer with
+    `part_stride` floats per row and at least 2 * M / 64 rows.  Returns the tensors the separate launches would have produced."""
+    from ._lib import BlockChainBwdArgs
+    a = BlockChainBwdArgs()
+    a.mode, a.M, a.C = mode, M, Cd
+    bf, f32 = torch.bfloat16, torch.float32
+    has_q, has_2 = mode in (0, 2), mode in (0, 1)
+    dev = (dqkv if has_q else g_in).device
+    out = {}
+
+    def new(name, shape, dtype=bf):
+        t = out[name] = torch.empty(shape, dtype=dtype, device=dev)
+        return t.data_ptr()
+
+    def inp(t, name, dtype, n=None):
+        _chk(t, name, dtype)
+        if n is not None and t.numel() != n:
+            raise RuntimeError(f"block_chain_bwd: {name} must hold {n} values, got {t.numel()}")
+        return t.data_ptr()
+
+    def part(t, name, n):
+        _chk(t, name, f32, contiguous=False)
+        if t.numel() != n:
+            raise RuntimeError(f"block_chain_bwd: {name} must be a row of {n} partial sums, got {t.numel()}")
+        return t.data_ptr()
+    if has_q:
+        a.dqkv, a.wqkvT = inp(dqkv, "dqkv", bf, M * 3 * Cd), inp(wqkvT, "wqkvT", bf, 3 * Cd * Cd)
+        a.x, a.mean1, a.rstd1, a.ln1w = inp(x, "x", f32, M * Cd), inp(mean1, "mean1", f32, M), inp(rstd1, "rstd1", f32, M), inp(ln1w, "ln1w", f32, Cd)
+        a.dresid1 = inp(dresid1, "dresid1", bf, M * Cd)
+        a.dx1, a.g1 = new("dx1", (M, Cd)), new("g1", (M, Cd))
+        a.dln1w_part, a.dln1b_part = part(dln1w_part, "dln1w_part", Cd), part(dln1b_part, "dln1b_part", Cd)
+        a.gbias1_part = part(gbias1_part, "gbias1_part", Cd) if gbias1_part is not None else None
+    if has_2:
+        if mode == 1:
+            a.g_in = inp(g_in, "g_in", bf, M * Cd)
+        a.w2T, a.w1T, a.wprojT = inp(w2T, "w2T", bf, 4 * Cd * Cd), inp(w1T, "w1T", bf, 4 * Cd * Cd), inp(wprojT, "wprojT", bf, Cd * Cd)
+        _chk(bits, "bits", torch.uint8)
+        a.sign_bits, a.sign_bits_bytes = bits.data_ptr(), bits.numel()
+        a.df = new("df", (M, 4 * Cd))
+        a.db1_part = part(db1_part, "db1_part", 4 * Cd)
+        a.x1, a.mean2, a.rstd2, a.ln2w = inp(x1, "x1", f32, M * Cd), inp(mean2, "mean2", f32, M), inp(rstd2, "rstd2", f32, M), inp(ln2w, "ln2w", f32, Cd)
+        a.dresid2 = out["dx1"].data_ptr() if mode == 0 else inp(dresid2, "dresid2", bf, M * Cd)
+        a.dx2, a.g2, a.dout = new("dx2", (M, Cd)), new("g2", (M, Cd)), new("dout", (M, Cd))
+        a.dln2w_part, a.dln2b_part = part(dln2w_part, "dln2w_part", Cd), part(dln2b_part, "dln2b_part", Cd)
+        a.gbias2_part = part(gbias2_part, "gbias2_part", Cd)
+    a.part_stride = int(part_stride)
+    a.dropout_p = float(dropout_p)
+    a.rng_state = _p(rng_state) if dropout_p > 0.0 else None
+    a.site_ffn_below, a.site_proj = site_ffn_below, site_proj
+    check(lib.dg_block_chain_bwd(C.byref(a), _stream()), "dg_block_chain_bwd")
+    return out

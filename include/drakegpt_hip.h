@@ -45,7 +45,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 15   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 16   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -393,6 +393,40 @@ int dg_block_chain_fwd(const dg_block_chain_args* args, void* stream);
 int dg_l2_warm(const void* p, int64_t bytes, void* stream);
 int dg_pack_chain_weights(const void* w, int64_t ld, void* packed, int N, int K, void* stream);
 int dg_pack_chain_weights_batched(const int64_t* desc, int n_desc, int total_stages, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The row-local chain of the BACKWARD pass between two attention-backward calls in ONE launch (bf16 operands and gradient
+ * stream, C = 384, M % 64 == 0, M / 64 <= #CUs) -- ref: autograd through src/model_component.py:392-393,404 (dX of the packed
+ * q / k / v Linears), :505 (LayerNorm 1 + residual branch), :324 (the Dropout of the block below), :322-323 (dX of the
+ * second FFN Linear through the ReLU), :321 (dX of the first), :506 (LayerNorm 2 + residual branch), :454 (proj's Dropout, dX):
+ *   [block l]     dh  = dqkv wqkvT        dx1 = LN'(dh; x, mean1, rstd1, ln1w) + dresid1       g1 = dropout_bwd(dx1; site_ffn_below)
+ *   [block l - 1] df  = (g1 w2T) masked by sign_bits      dh2 = df w1T
+ *                 dx2 = LN'(dh2; x1, mean2, rstd2, ln2w) + dx1      g2 = dropout_bwd(dx2; site_proj)      dout = g2 wprojT
+ * It replaces four dg_gemm_nt launches and two dg_layernorm_bwd_fused launches and leaves what they left: df, g1, g2 (the dY
+ * operands of the weight gradients), dx1 / dx2 (the bf16 gradient stream), dout (the attention backward's input) and the
+ * partial rows of b1 (column sums of df), b2 / bproj (column sums of g1 / g2) and both LayerNorms' dgamma / dbeta: TWO rows
+ * per 64-row block, row 2 * block + {0, 1} at `part_stride` floats (2 * M / 64 rows for dg_reduce_partials).  The LayerNorm
+ * backward consumes the dX GEMM's fp32 accumulators (the separate launches round them to bf16 in between).  The four weight
+ * operands are the W^T shadows ([in, out] bf16) PACKED by dg_pack_chain_weights (wqkvT: N = C, K = 3C; w2T: N = 4C, K = C;
+ * w1T: N = C, K = 4C; wprojT: N = C, K = C).  sign_bits: dg_gemm_nt's layout for an [M, 4C] output.
+ * mode 0: everything above (dresid2 is dx1: pass the same pointer).  mode 1 (top of the stack): the second half only, g1
+ * arrives as g_in.  mode 2 (block 0): the first half only; gbias1_part NULL = no dropout and no bias behind LayerNorm 1. */
+typedef struct dg_block_chain_bwd_args {
+    int32_t mode, M, C, reserved;
+    const void* dqkv; const void* wqkvT; const float* x; const float* mean1; const float* rstd1; const float* ln1w;
+    const void* dresid1; void* dx1; void* g1;
+    float* dln1w_part; float* dln1b_part; float* gbias1_part;
+    const void* g_in;
+    const void* w2T; const uint8_t* sign_bits; int64_t sign_bits_bytes; void* df; float* db1_part;
+    const void* w1T; const float* x1; const float* mean2; const float* rstd2; const float* ln2w;
+    const void* dresid2; void* dx2; void* g2;
+    float* dln2w_part; float* dln2b_part; float* gbias2_part;
+    const void* wprojT; void* dout;
+    int64_t part_stride;
+    float dropout_p; const uint32_t* rng_state; uint32_t site_ffn_below, site_proj;
+} dg_block_chain_bwd_args;
+int dg_block_chain_bwd_supported(int M, int C);
+int dg_block_chain_bwd(const dg_block_chain_bwd_args* args, void* stream);
 
 #ifdef __cplusplus
 }

@@ -376,7 +376,7 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("switch", ["DG_CHAIN_LN", "DG_CHAIN"])
+@pytest.mark.parametrize("switch", ["DG_CHAIN_LN", "DG_CHAIN", "DG_CHAIN_BWD"])
 @pytest.mark.parametrize("p", [0.0, 0.2])
 def test_layernorm_inside_gemm_epilogue_equals_separate_launches(dev, p, switch):
     """round 3: proj + residual + LayerNorm 2 and FFN2 + residual + the next block's LayerNorm 1 as row-complete GEMMs whose
@@ -386,7 +386,9 @@ def test_layernorm_inside_gemm_epilogue_equals_separate_launches(dev, p, switch)
     row statistics combined from four 96-column partials instead of one wave-wide sum -- differences at fp32 rounding level in
     mean / rstd, an occasional bf16 ulp in the normalised activations.  Also the packed-weight refresh after the optimizer step
     (second step: Adam's first update is lr * sign(g), so gradients that differ in the last bit near zero move weights apart by
-    2 lr -- the second step's bounds are those of two bf16 runs, not of one kernel) and the forward-only evaluation path."""
+    2 lr -- the second step's bounds are those of two bf16 runs, not of one kernel) and the forward-only evaluation path.
+    DG_CHAIN_BWD=1: the backward pass's row-local chain (dg_block_chain_bwd modes 1 / 0 / 2: dX GEMMs with the LayerNorm backward in
+    the epilogue, two partial rows per 64-row block for the bias / LayerNorm gradients) against the separate launches."""
     import drakegpt_amd as D
     from drakegpt_amd.engine import TrainEngine
     B, T, C, NH, L = 8, 256, 384, 6, 3
@@ -405,7 +407,7 @@ def test_layernorm_inside_gemm_epilogue_equals_separate_launches(dev, p, switch)
         finally:
             os.environ.pop(switch, None)
             os.environ.pop("DG_CHAIN", None)
-        assert (eng.chain_ln if switch == "DG_CHAIN_LN" else eng.chain_full) == (mode == "1")
+        assert {"DG_CHAIN_LN": eng.chain_ln, "DG_CHAIN": eng.chain_full, "DG_CHAIN_BWD": eng.chain_bwd}[switch] == (mode == "1")
         if switch == "DG_CHAIN_LN":
             assert not eng.chain_full
         eng.keep_logits = True
