@@ -172,7 +172,11 @@ def main():
                                                      ("gpt2_small_B8", "gpt2_small", 8, None, 8, 3, "bf16"),
                                                      ("gpt2_small_B16", "gpt2_small", 16, None, 5, 2, "bf16"),
                                                      ("gpt2_medium_B8_bf16", "gpt2_medium", 8, None, 5, 2, "bf16"),
-                                                     ("gpt2_medium_B8_fp8", "gpt2_medium", 8, None, 5, 2, "fp8")):
+                                                     ("gpt2_medium_B8_fp8", "gpt2_medium", 8, None, 5, 2, "fp8"),
+                                                     # BASELINE configs[4] names no batch: 288 GB hold far more than 8 sequences, and the fp8
+                                                     # path pays more the larger the GEMMs (same box: 1.21x at B = 8, 1.25x at 16, 1.29x at 32)
+                                                     ("gpt2_medium_B32_bf16", "gpt2_medium", 32, None, 3, 2, "bf16"),
+                                                     ("gpt2_medium_B32_fp8", "gpt2_medium", 32, None, 3, 2, "fp8")):
             try:
                 extra[name] = run_extra(cname, b, p_drop, st, wu, dev, prec)
                 log(f"extra {name}: {extra[name]['value']:.0f} tokens/s, {extra[name]['ms_per_step']:.3f} ms/step")
@@ -309,6 +313,15 @@ def kernel_roofline(eng, offsets, peak_tflops):
         sym = "gemm_tn_grouped_kernel" if os.environ.get("DG_TN_TILE") == "128" else f"gemm_tn_grouped256_kernel<{1 if os.environ.get('DG_TN_WAVETILE') == '1' else 0},{f8}>"
         calls.append((sym, fl, lambda: real_tng(problems, workspace)))
 
+    # the row-local chain of a residual block as one launch (round 3: the forward default at C = 384): its GEMM pieces' FLOP
+    real_chain = ops.block_chain_fwd
+
+    def chain(mode, M, Cd, **kw):
+        r = real_chain(mode, M, Cd, **kw)
+        per = {0: 24.0, 1: 18.0, 2: 6.0, 3: 2.0, 4: 8.0}[mode]          # 2 M C (C + 4C + 4C + 3C) for the whole chain
+        calls.append((f"block_chain_fwd_kernel<{mode}>", per * M * Cd * Cd, lambda: real_chain(mode, M, Cd, **kw)))
+        return r
+
     # HBM-bound kernels: algorithmic bytes per launch (what the kernel must read + write once; SURVEY 8d conventions)
     hbm = []              # (symbol, bytes, closure)
     esz = lambda t: t.element_size()
@@ -343,7 +356,7 @@ def kernel_roofline(eng, offsets, peak_tflops):
         "batch_embed_fwd": wrap("batch_embed_fwd", lambda r, corpus, offs, st, ctl, x, y, tok, pos, onehot=None: r.numel() * 4 + x.numel() * 32 + (onehot.numel() * 2 if onehot is not None else 0)),
     }
     eng.set_offsets(offsets)
-    ops.gemm_nt, ops.gemm_tn, ops.gemm_tn_grouped = nt, tn, tng
+    ops.gemm_nt, ops.gemm_tn, ops.gemm_tn_grouped, ops.block_chain_fwd = nt, tn, tng, chain
     for n_, f_ in wrapped.items():
         setattr(ops, n_, f_)
     try:
@@ -351,7 +364,7 @@ def kernel_roofline(eng, offsets, peak_tflops):
         eng._prog_update()
         torch.cuda.synchronize()
     finally:
-        ops.gemm_nt, ops.gemm_tn, ops.gemm_tn_grouped = real_nt, real_tn, real_tng
+        ops.gemm_nt, ops.gemm_tn, ops.gemm_tn_grouped, ops.block_chain_fwd = real_nt, real_tn, real_tng, real_chain
         for n_, f_ in real_hbm.items():
             setattr(ops, n_, f_)
     snap = (eng.flat.clone(), eng.m_.clone(), eng.v_.clone())       # the AdamW replays below must not train the model away
