@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma2_kernel(AttnP p) {
 
 // =============================================================================================
 // dQ: wave = 32 queries; per key tile: S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T
-#define WAVE_LDS_DQ 12288
+#define WAVE_LDS_DQ 13312     // K row image, K transposed-read image, V row image (4 KB each) + 1 KB: the first Q fragment, parked
 // Without dropout the compiler wants 208 registers for this loop (everything of a tile in flight at once); capped at 168 (three
 // workgroups per CU) it spilled 39 of them inside the loop: 56.6 us per layer against 36.4 us WITH dropout, which made a
 // dropout-0 step slower than a dropout-0.2 step.  The no-dropout variant therefore takes two workgroups per CU and no spills.
@@ -464,6 +464,12 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
     bf16x8 qf[4], gf[4];
     frags_global(qf, Qb, ld, q0, T, lane);
     frags_global(gf, dOb, C, q0, T, lane);
+    // The loop below is five registers over its budget of 168, and the allocator's answer was to spill qf[0] to scratch and reload it
+    // at the top of every tile: a scratch load is a vector-memory operation, `vmcnt` counts in order, so its `s_waitcnt vmcnt(0)`
+    // also waited for the NEXT tile's K / V prefetch issued just before it -- a full global round trip exposed per tile.  The
+    // fragment is parked in the wave's LDS slice instead (1 KB) and read back with the K fragments of each tile.
+    char* imgQ0 = smem + wave * WAVE_LDS_DQ + 12288;
+    *(bf16x8*)(imgQ0 + lane * 16) = qf[0];
     const float L2 = p.lse_r[bh * T + (qi < T ? qi : T - 1)] * LOG2E;
     // delta_i = sum_d dO[i,d] O[i,d]: this lane holds half of row i of dO as MFMA fragments; dot it with the
     // matching half of O and add the other half-wave's part.  Written out for the dK/dV pass that follows.
@@ -508,7 +514,8 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
         for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgK, ks, ln), qf[ks], S, 0, 0, 0);
+            const bf16x8 qk = ks == 0 ? *(const bf16x8*)(imgQ0 + ln * 16) : qf[ks];
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgK, ks, ln), qk, S, 0, 0, 0);
             dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgV, ks, ln), gf[ks], dP, 0, 0, 0);
         }
         const int k0 = kt * TILE;
