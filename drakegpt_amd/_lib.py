@@ -18,7 +18,7 @@ DG_F32 = 0
 DG_BF16 = 1
 DG_FP8_E4M3 = 2
 DG_FP8_E5M2 = 3
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class GemmNtArgs(C.Structure):
@@ -128,8 +128,9 @@ SIGNATURES = {
     "dg_cast": [_vp, _i, _vp, _i, _i64, _vp],
     "dg_transpose_cast": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp],
     "dg_transpose_cast_batched": [_vp, _i, _i, _i, _i, _vp],
-    "dg_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
-    "dg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp],
+    "dg_attn_keep_bits_bytes": [_i, _i, _i, _i, _i],
+    "dg_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp, _i64, _vp],
+    "dg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp, _i64, _vp],
     "dg_attn_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
     "dg_attn_decode": [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dg_cross_entropy": [_vp, _i, _i64, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _i, _vp],
@@ -164,6 +165,7 @@ def _load() -> C.CDLL:
     lib.dg_gemm_nt_sign_bits_bytes.restype = C.c_int64
     lib.dg_gemm_tn_grouped_workspace_bytes.restype = C.c_int64
     lib.dg_attn_bwd_workspace_bytes.restype = C.c_int64
+    lib.dg_attn_keep_bits_bytes.restype = C.c_int64
     lib.dg_error_string.argtypes = [C.c_int]
     lib.dg_error_string.restype = C.c_char_p
     v = lib.dg_version()

@@ -5,18 +5,25 @@
 int dg_attn_fwd_simple(const void*, void*, float*, int, int, int, int, float, float, const uint32_t*, uint32_t, int, hipStream_t);
 int dg_attn_bwd_simple(const void*, const void*, const void*, const float*, void*, float*, int, int, int, int, float, float,
                        const uint32_t*, uint32_t, int, hipStream_t);
-int dg_attn_fwd_mfma(const void*, void*, float*, int, int, int, int, float, float, const uint32_t*, uint32_t, hipStream_t);
+int dg_attn_fwd_mfma(const void*, void*, float*, int, int, int, int, float, float, const uint32_t*, uint32_t, void*, hipStream_t);
 int dg_attn_bwd_mfma(const void*, const void*, const void*, const float*, void*, float*, void*, int, int, int, int, float, float,
-                     const uint32_t*, uint32_t, hipStream_t);
+                     const uint32_t*, uint32_t, const void*, hipStream_t);
+int64_t dg_attn_mfma_keep_bytes(int B, int T, int NH);
 int64_t dg_attn_bwd_mfma_tile_bytes(int B, int T, int NH);
 bool dg_attn_mfma_supported(int B, int T, int NH, int H);
 
+extern "C" int64_t dg_attn_keep_bits_bytes(int B, int T, int NH, int H, int dtype) {
+    if (B <= 0 || T <= 0 || NH <= 0) return 0;
+    return (dtype == DG_BF16 && dg_attn_mfma_supported(B, T, NH, H)) ? dg_attn_mfma_keep_bytes(B, T, NH) : 0;
+}
+
 extern "C" int dg_attn_fwd(const void* qkv, void* out, float* lse, int B, int T, int NH, int H,
                            float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
-                           int dtype, void* stream) {
+                           int dtype, void* keep_bits, int64_t keep_bits_bytes, void* stream) {
     if (!qkv || !out || !lse) return DG_ERR_ARG;
+    if (keep_bits && keep_bits_bytes < dg_attn_keep_bits_bytes(B, T, NH, H, dtype)) return DG_ERR_ARG;
     if (dtype == DG_BF16 && dg_attn_mfma_supported(B, T, NH, H))
-        return dg_attn_fwd_mfma(qkv, out, lse, B, T, NH, H, scale, dropout_p, rng_state, site, (hipStream_t)stream);
+        return dg_attn_fwd_mfma(qkv, out, lse, B, T, NH, H, scale, dropout_p, rng_state, site, keep_bits, (hipStream_t)stream);
     return dg_attn_fwd_simple(qkv, out, lse, B, T, NH, H, scale, dropout_p, rng_state, site, dtype, (hipStream_t)stream);
 }
 
@@ -32,13 +39,14 @@ extern "C" int64_t dg_attn_bwd_workspace_bytes(int B, int T, int NH, int H, int 
 extern "C" int dg_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                            void* dqkv, void* workspace, int64_t workspace_bytes, int B, int T, int NH, int H,
                            float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
-                           int dtype, void* stream) {
+                           int dtype, const void* keep_bits, int64_t keep_bits_bytes, void* stream) {
     if (!qkv || !out || !dout || !lse || !dqkv || !workspace) return DG_ERR_ARG;
+    if (keep_bits && keep_bits_bytes < dg_attn_keep_bits_bytes(B, T, NH, H, dtype)) return DG_ERR_ARG;
     if (B <= 0 || T <= 0 || NH <= 0 || workspace_bytes < (int64_t)B * NH * T * 4 || !dg_aligned16(workspace)) return DG_ERR_ARG;
     float* delta_ws = (float*)workspace;
     if (dtype == DG_BF16 && dg_attn_mfma_supported(B, T, NH, H)) {
         void* tiles = workspace_bytes >= dg_attn_bwd_workspace_bytes(B, T, NH, H, dtype) ? (char*)workspace + attn_delta_bytes(B, T, NH) : nullptr;
-        return dg_attn_bwd_mfma(qkv, out, dout, lse, dqkv, delta_ws, tiles, B, T, NH, H, scale, dropout_p, rng_state, site, (hipStream_t)stream);
+        return dg_attn_bwd_mfma(qkv, out, dout, lse, dqkv, delta_ws, tiles, B, T, NH, H, scale, dropout_p, rng_state, site, keep_bits, (hipStream_t)stream);
     }
     return dg_attn_bwd_simple(qkv, out, dout, lse, dqkv, delta_ws, B, T, NH, H, scale, dropout_p, rng_state, site, dtype, (hipStream_t)stream);
 }

@@ -38,8 +38,16 @@ struct AttnP {
     int balance, rot_div;      // balance: 0 plain, 1 = cost-balanced item order (nblk % 4 == 0); rot_div = #CUs
     int xcd;                   // 1 = the workgroups of one (batch, head) land on one XCD (balanced order only)
     char* tiles;               // optional: [B*NH][nblk(nblk+1)/2] tiles, see attn_bwd_dq_mfma_kernel
+    // optional (round 3): the keep decisions of the dropout, left by the forward pass as 16 wave masks (64 bits: one per lane) per
+    // 32 x 32 tile -- mask r, lane (c, hh) = element (query q0 + c, key k0 + krow(r, hh)), the layout both the forward kernel and
+    // the dQ pass hold a tile in -- so that the dQ pass selects with scalar masks instead of hashing 16 keys per lane again
+    unsigned long long* keep;
+    unsigned long long* stamps;  // diagnostic (tools/attn_dq_stamps.py): per workgroup 8 words = cycles wave 0 spent in each phase of the dQ tile loop; NULL in production
     int tiles_mode;            // 1: 4 KB tiles [32 q][P | dS] (LDS-staged); 2: 2 KB tiles, the lanes' 16 signed probabilities as they hold them
 };
+__device__ __forceinline__ int64_t attn_keep_index(const AttnP& p, int64_t bh, int qb, int kb) {       // in 128-byte records
+    return bh * (p.nblk * (p.nblk + 1) / 2) + qb * (qb + 1) / 2 + kb;
+}
 __device__ __forceinline__ int64_t attn_tile_index(const AttnP& p, int64_t bh, int qb, int kb) {
     return (bh * (p.nblk * (p.nblk + 1) / 2) + qb * (qb + 1) / 2 + kb) * (p.tiles_mode == 2 ? 2048 : 4096);
 }
@@ -172,7 +180,7 @@ __device__ __forceinline__ void store_N_acc(char* img, const f32x16 (&acc)[2], f
 
 #define WAVE_LDS_FWD 8192
 // =============================================================================================
-template <bool DROP>      // dropout on the probabilities (compile-time: no per-element uniform branch)
+template <bool DROP, bool KEEP = false>      // dropout on the probabilities (compile-time: no per-element uniform branch); KEEP: also leave the keep masks (AttnP::keep)
 __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block, pointers and loop bounds live in SGPRs
@@ -237,16 +245,47 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
         const float alpha = __builtin_amdgcn_exp2f(m - mn);
         m = mn;
         float ps = 0.f;
+        unsigned long long km[16];                          // (KEEP) the sixteen compare masks of this tile
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {                   // registers r, r + 1 = adjacent keys = one hash pair
             float e0 = __builtin_amdgcn_exp2f(S[r] - mn), e1 = __builtin_amdgcn_exp2f(S[r + 1] - mn);
             ps += e0 + e1;
             if (DROP) {
                 const uint32_t x = dg_hash_w(key, wtile + (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2)) * DG_WEYL);
-                e0 = dg_keep_lo(x, p.thr) ? e0 * p.inv_keep : 0.f;
-                e1 = dg_keep_hi(x, p.thr) ? e1 * p.inv_keep : 0.f;
+                const bool k0b = dg_keep_lo(x, p.thr), k1b = dg_keep_hi(x, p.thr);
+                e0 = k0b ? e0 * p.inv_keep : 0.f;
+                e1 = k1b ? e1 * p.inv_keep : 0.f;
+                if (KEEP) { km[r] = __builtin_amdgcn_ballot_w64(k0b); km[r + 1] = __builtin_amdgcn_ballot_w64(k1b); }
             }
             S[r] = e0; S[r + 1] = e1;
+        }
+        if (DROP && KEEP) {
+            // The masks sit in SGPRs (the compares wrote them); dword i of the tile's 128-byte record goes to lane i of one register
+            // and 32 lanes store it.  v_writelane reading an SGPR that a VALU compare has just written needs wait states the
+            // compiler does not insert in front of inline asm (the last mask came out wrong on 28 of 32 lanes): all writes in two
+            // blocks behind the whole score loop, the first one behind an s_nop.
+            uint32_t kbv = 0;
+            uint32_t w[32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { w[2 * r] = (uint32_t)km[r]; w[2 * r + 1] = (uint32_t)(km[r] >> 32); }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 4\n\t"
+                         "v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+                         "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7\n\t"
+                         "v_writelane_b32 %0, %9, 8\n\tv_writelane_b32 %0, %10, 9\n\tv_writelane_b32 %0, %11, 10\n\tv_writelane_b32 %0, %12, 11\n\t"
+                         "v_writelane_b32 %0, %13, 12\n\tv_writelane_b32 %0, %14, 13\n\tv_writelane_b32 %0, %15, 14\n\tv_writelane_b32 %0, %16, 15"
+                         : "+v"(kbv)
+                         : "s"(w[0]), "s"(w[1]), "s"(w[2]), "s"(w[3]), "s"(w[4]), "s"(w[5]), "s"(w[6]), "s"(w[7]), "s"(w[8]), "s"(w[9]), "s"(w[10]),
+                           "s"(w[11]), "s"(w[12]), "s"(w[13]), "s"(w[14]), "s"(w[15]));
+            asm volatile("s_nop 4\n\t"
+                         "v_writelane_b32 %0, %1, 16\n\tv_writelane_b32 %0, %2, 17\n\tv_writelane_b32 %0, %3, 18\n\tv_writelane_b32 %0, %4, 19\n\t"
+                         "v_writelane_b32 %0, %5, 20\n\tv_writelane_b32 %0, %6, 21\n\tv_writelane_b32 %0, %7, 22\n\tv_writelane_b32 %0, %8, 23\n\t"
+                         "v_writelane_b32 %0, %9, 24\n\tv_writelane_b32 %0, %10, 25\n\tv_writelane_b32 %0, %11, 26\n\tv_writelane_b32 %0, %12, 27\n\t"
+                         "v_writelane_b32 %0, %13, 28\n\tv_writelane_b32 %0, %14, 29\n\tv_writelane_b32 %0, %15, 30\n\tv_writelane_b32 %0, %16, 31"
+                         : "+v"(kbv)
+                         : "s"(w[16]), "s"(w[17]), "s"(w[18]), "s"(w[19]), "s"(w[20]), "s"(w[21]), "s"(w[22]), "s"(w[23]), "s"(w[24]), "s"(w[25]),
+                           "s"(w[26]), "s"(w[27]), "s"(w[28]), "s"(w[29]), "s"(w[30]), "s"(w[31]));
+            if (lane < 32) ((uint32_t*)p.keep)[attn_keep_index(p, bh, qb, kt) * 32 + lane] = kbv;
         }
         lsum = lsum * alpha + ps;
 #pragma unroll
@@ -440,7 +479,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma2_kernel(AttnP p) {
 // workgroups per CU) it spilled 39 of them inside the loop: 56.6 us per layer against 36.4 us WITH dropout, which made a
 // dropout-0 step slower than a dropout-0.2 step.  The no-dropout variant therefore takes two workgroups per CU and no spills.
 // TM: what the pass leaves behind for the dK/dV pass -- 0 nothing, 1 the [32 q][P | dS] tiles, 2 the signed probabilities only
-template <bool DROP, int TM>      // dropout on the probabilities (compile-time: no per-element uniform branch)
+// KB: the keep decisions come as wave masks from the forward pass (AttnP::keep) instead of being hashed again
+template <bool DROP, int TM, bool KB = false>      // dropout on the probabilities (compile-time: no per-element uniform branch)
 __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block, pointers and loop bounds live in SGPRs
@@ -495,12 +535,33 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
     u32x4 rk[4], rv[4];
     tile_load(rk, Kb, ld, 0, T, lane);
     tile_load(rv, Vb, ld, 0, T, lane);
+    unsigned long long st_prev = 0, st_acc[5] = {0, 0, 0, 0, 0};
+    const bool st_on = p.stamps != nullptr && wave == 0;          // (wave-uniform)
+    auto stamp = [&](int k) {
+        if (st_on) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (k >= 0) st_acc[k] += t - st_prev;
+            st_prev = t;
+        }
+    };
+    stamp(-1);
     for (int kt = 0; kt <= qb; ++kt) {
         // LDS / global addresses are recomputed from the lane id every iteration (opaque to the optimiser) instead of being
         // hoisted into ~20 loop-invariant VGPRs: the kernel wants 186-219 VGPRs otherwise, and at three workgroups per CU
         // (168) the overflow went to scratch (no-dropout variant: 68 spilled registers, 65 -> 55 us for the backward pair).
         int ln = lane;
         asm volatile("" : "+v"(ln));
+        // (KB) this tile's 16 wave masks = 128 bytes at a wave-uniform address: two scalar loads, requested here, waited for in front
+        // of the score arithmetic.  Written as asm: the compiler cannot prove that none of the kernel's own stores alias the record
+        // and turns a plain load into eight vector loads (32 VGPRs, all spilled) + readfirstlanes.
+        typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+        u32x16 mkA, mkB;
+        if (KB) {
+            const unsigned long long a = (unsigned long long)(p.keep + attn_keep_index(p, bh, qb, kt) * 16);
+            const uint32_t alo = __builtin_amdgcn_readfirstlane((uint32_t)a), ahi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+            const unsigned long long ua = ((unsigned long long)ahi << 32) | alo;
+            asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(mkA), "=&s"(mkB) : "s"(ua) : "memory");
+        }
         tile_store<false>(imgK, rk, ln);
         tile_store<true>(imgKt, rk, ln);
         tile_store<false>(imgV, rv, ln);
@@ -509,6 +570,7 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
             tile_load(rv, Vb, ld, (kt + 1) * TILE, T, ln);
         }
         __builtin_amdgcn_wave_barrier();
+        stamp(0);
         f32x16 S, dP;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
@@ -518,6 +580,7 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
             S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgK, ks, ln), qk, S, 0, 0, 0);
             dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgV, ks, ln), gf[ks], dP, 0, 0, 0);
         }
+        stamp(1);
         const int k0 = kt * TILE;
         const uint32_t wtile = wbase + (uint32_t)(k0 >> 1) * DG_WEYL;
         // With p.tiles the (dropped-out) probabilities and dS of this 32 x 32 tile are also written out, side by side as a
@@ -526,6 +589,7 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
         // 1 KB rows per instruction.
         constexpr bool emit = TM == 1, emit2 = TM == 2;
         const bool rows_ok = q0 + TILE <= T;
+        if (KB) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mkA), "+s"(mkB));
         bf16x8 p2[2];                                              // (tiles_mode 2) this lane's 16 signed probabilities
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -538,7 +602,10 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
                 float pr = __builtin_amdgcn_exp2f(S[r] * sc - L2);
                 if (kt == qb && kj > qi) pr = 0.f;
                 float kf = 1.f;
-                if (DROP) {
+                if (DROP && KB) {
+                    const uint32_t mlo = r < 8 ? mkA[2 * (r & 7)] : mkB[2 * (r & 7)], mhi = r < 8 ? mkA[2 * (r & 7) + 1] : mkB[2 * (r & 7) + 1];
+                    kf = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)mhi << 32) | mlo) ? p.inv_keep : 0.f;
+                } else if (DROP) {
                     // Keys j, j + 1 of this run read the two fields of one hash word, but the word is hashed again for
                     // each: holding it across the pair costs this kernel 43 spilled registers (measured, +3 us per
                     // layer), so the pair saving is taken in the forward kernels only.  `zs` (a run-time zero) on
@@ -565,7 +632,11 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
                 *(bf16x4*)(imgV + c * 128 + ((g ^ (c & 7)) << 4) + 8 * hh) = pv;
                 *(bf16x4*)(imgV + c * 128 + (((4 + g) ^ (c & 7)) << 4) + 8 * hh) = dv;
             }
+            // (KB) without the hash chains to order it the scheduler interleaves all sixteen scores and spills 34-51 registers: one
+            // group of four at a time
+            if (KB) __builtin_amdgcn_sched_barrier(0);
         }
+        stamp(2);
         if (emit) {
             __builtin_amdgcn_wave_barrier();
             char* tb = p.tiles + attn_tile_index(p, bh, qb, kt);
@@ -580,6 +651,7 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
             *(bf16x8*)tb = p2[0];
             *(bf16x8*)(tb + 16) = p2[1];
         }
+        stamp(3);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const bf16x8 df = pack8(S, s);
@@ -588,6 +660,12 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
                 dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(imgKt, dt, s, ln), df, dQ[dt], 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
+        stamp(4);
+    }
+    if (st_on && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) p.stamps[(int64_t)blockIdx.x * 8 + k] = st_acc[k];
+        p.stamps[(int64_t)blockIdx.x * 8 + 5] = (unsigned long long)(qb + 1);
     }
     store_T_acc(imgK, dQ, p.scale, p.dqkv + (int64_t)b * T * ld + h * HD, ld, q0, T, lane);
 }
@@ -886,7 +964,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_ptiles_kernel(AttnP p) {
     store_N_acc(imgQt, dV, 1.f, dKb + C, ld, k0, T, lane);
 }
 
+static unsigned long long* g_attn_stamps = nullptr;
+// diagnostic only (tools/attn_dq_stamps.py): not part of the public header
+extern "C" void dg_debug_set_attn_stamps(void* q) { g_attn_stamps = (unsigned long long*)q; }
+
 static void fill(AttnP& p, int B, int T, int NH, float scale, float dp, const uint32_t* rng, uint32_t site) {
+    p.stamps = g_attn_stamps;
     p.B = B; p.T = T; p.NH = NH; p.nblk = (T + TILE - 1) / TILE;
     p.n_items = (int64_t)B * NH * p.nblk;
     p.scale = scale;
@@ -906,22 +989,29 @@ static void fill(AttnP& p, int B, int T, int NH, float scale, float dp, const ui
     p.xcd = xcd;
 }
 
+int64_t dg_attn_mfma_keep_bytes(int B, int T, int NH) {
+    const int64_t nblk = (T + TILE - 1) / TILE;
+    return (int64_t)B * NH * (nblk * (nblk + 1) / 2) * 128;
+}
+
 int dg_attn_fwd_mfma(const void* qkv, void* out, float* lse, int B, int T, int NH, int H, float scale, float dp,
-                     const uint32_t* rng, uint32_t site, hipStream_t s) {
-    if (dp < 0.f || dp >= 1.f || !dg_aligned16(qkv) || !dg_aligned16(out)) return DG_ERR_ARG;
+                     const uint32_t* rng, uint32_t site, void* keep, hipStream_t s) {
+    if (dp < 0.f || dp >= 1.f || !dg_aligned16(qkv) || !dg_aligned16(out) || (keep && !dg_aligned16(keep))) return DG_ERR_ARG;
     AttnP p = {};
     fill(p, B, T, NH, scale, dp, rng, site);
     p.qkv = (const bf16_t*)qkv; p.out_w = (bf16_t*)out; p.lse = lse;
+    p.keep = (unsigned long long*)keep;
     dim3 grid((unsigned)((p.n_items + 3) / 4)), block(256);
     static const int shared_mode = [] { const char* e = getenv("DG_ATTN_SHARED"); return e ? atoi(e) : 0; }();   // 1 = shared 64-key tiles (measured slower, see attn_fwd_mfma2_kernel)
-    if (shared_mode && p.balance && T % 64 == 0) {      // balance: nblk % 4 == 0, i.e. T % 128 == 0 (whole 64-key tiles)
+    if (shared_mode && p.balance && T % 64 == 0 && !keep) {      // balance: nblk % 4 == 0, i.e. T % 128 == 0 (whole 64-key tiles)
         if (p.drop) hipLaunchKernelGGL(attn_fwd_mfma2_kernel<true>, grid, block, 2 * FWD2_BUF, s, p);
         else hipLaunchKernelGGL(attn_fwd_mfma2_kernel<false>, grid, block, 2 * FWD2_BUF, s, p);
         DG_LAUNCH_CHECK();
         return DG_OK;
     }
-    if (p.drop) hipLaunchKernelGGL(attn_fwd_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_FWD, s, p);
-    else hipLaunchKernelGGL(attn_fwd_mfma_kernel<false>, grid, block, 4 * WAVE_LDS_FWD, s, p);
+    if (p.drop && p.keep) hipLaunchKernelGGL((attn_fwd_mfma_kernel<true, true>), grid, block, 4 * WAVE_LDS_FWD, s, p);
+    else if (p.drop) hipLaunchKernelGGL((attn_fwd_mfma_kernel<true, false>), grid, block, 4 * WAVE_LDS_FWD, s, p);
+    else hipLaunchKernelGGL((attn_fwd_mfma_kernel<false, false>), grid, block, 4 * WAVE_LDS_FWD, s, p);
     DG_LAUNCH_CHECK();
     return DG_OK;
 }
@@ -933,8 +1023,9 @@ int64_t dg_attn_bwd_mfma_tile_bytes(int B, int T, int NH) {
 }
 
 int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, void* tiles,
-                     int B, int T, int NH, int H, float scale, float dp, const uint32_t* rng, uint32_t site, hipStream_t s) {
+                     int B, int T, int NH, int H, float scale, float dp, const uint32_t* rng, uint32_t site, const void* keep, hipStream_t s) {
     if (dp < 0.f || dp >= 1.f || !dg_aligned16(qkv) || !dg_aligned16(out) || !dg_aligned16(dout) || !dg_aligned16(dqkv)) return DG_ERR_ARG;
+    if (keep && !dg_aligned16(keep)) return DG_ERR_ALIGN;
     if (tiles && !dg_aligned16(tiles)) return DG_ERR_ALIGN;
     AttnP p = {};
     fill(p, B, T, NH, scale, dp, rng, site);
@@ -943,6 +1034,9 @@ int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const f
     static const int tile_mode = [] { const char* e = getenv("DG_ATTN_TILES"); return e ? atoi(e) : 1; }();   // 1 = P | dS tiles (default), 2 = signed P tiles (measured slower), 0 = recompute in the dK/dV pass
     p.tiles = tile_mode ? (char*)tiles : nullptr;
     p.tiles_mode = tile_mode == 1 ? 1 : 2;
+    // keep masks from the forward pass: the default tile form (DG_ATTN_TILES=1) only; DG_ATTN_KEEPBITS=0 ignores them (A/B runs)
+    static const int keep_mode = [] { const char* e = getenv("DG_ATTN_KEEPBITS"); return e ? atoi(e) : 1; }();
+    p.keep = (keep_mode && keep && dp > 0.f && rng) ? (unsigned long long*)keep : nullptr;
     dim3 grid((unsigned)((p.n_items + 3) / 4)), block(256);
     // Without dropout the dQ pass still runs the DROP = true code with a threshold of 0 (every hash >= 0: keep everything) and
     // a keep scale of 1: bit-identical results, and 36 us per layer instead of the 48 us of the DROP = false variant (whose loop
@@ -954,7 +1048,8 @@ int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const f
         if (tm == 2) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DROP_, 2>), grid, block, 4 * WAVE_LDS_DQ, s, Q_); \
         else if (tm == 1) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DROP_, 1>), grid, block, 4 * WAVE_LDS_DQ, s, Q_); \
         else hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DROP_, 0>), grid, block, 4 * WAVE_LDS_DQ, s, Q_); } while (0)
-    if (p.drop) DQ_LAUNCH(true, p);
+    if (p.drop && p.keep && tm == 1) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, true>), grid, block, 4 * WAVE_LDS_DQ, s, p);
+    else if (p.drop) DQ_LAUNCH(true, p);
     else if (nodrop_variant) DQ_LAUNCH(false, p);
     else {
         AttnP q = p;

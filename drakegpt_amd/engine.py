@@ -575,7 +575,7 @@ class TrainEngine:
         r = ops.block_chain_fwd(2, M, C, x=h, ln1w=P["ln1w"], ln1b=P["ln1b"], wqkv=pk(P["wqkv"]))
         x, h1, m1, r1, qkv = h, r["h1"], r["mean1"], r["rstd1"], r["qkv"]
         for l in range(self.L):
-            o, lse = ops.attn_fwd(qkv, B, T, self.NH, self.H, self.H ** -0.5, p, run.rng, S.site_attn(l))
+            o, lse = ops.attn_fwd(qkv, B, T, self.NH, self.H, self.H ** -0.5, p, run.rng, S.site_attn(l), keep=want_grad)
             last = l == self.L - 1
             if self.chain_warm:
                 # the layer's packed weight stream (wproj | w1 | w2 | the next block's wqkv: contiguous in the packed buffer)

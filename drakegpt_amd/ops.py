@@ -505,27 +505,45 @@ def transpose_cast_batched(table: Tensor, n_desc: int, total_tiles: int, dtype: 
     check(lib.dg_transpose_cast_batched(_p(table), n_desc, total_tiles, dt_code(in_dtype), dt_code(dtype), _stream()), "dg_transpose_cast_batched")
 
 
-def attn_fwd(qkv: Tensor, B: int, T: int, NH: int, H: int, scale: float, p: float, rng_state: Optional[Tensor], site: int):
+def attn_fwd(qkv: Tensor, B: int, T: int, NH: int, H: int, scale: float, p: float, rng_state: Optional[Tensor], site: int,
+             keep: bool = False):
+    """keep=True (training with dropout, a backward pass follows): the forward pass also leaves its dropout keep decisions as
+    wave masks (dg_attn_keep_bits_bytes; 128 bytes per unmasked 32 x 32 tile) -- they travel with the output as its attribute
+    `dg_keep` and attn_bwd(..., keep_bits=out.dg_keep) selects with them instead of hashing again.  Shapes on the generic
+    kernels have no such path (no attribute is set)."""
     _chk(qkv, "qkv")
     if qkv.shape != (B * T, 3 * NH * H):
         raise RuntimeError(f"attn_fwd: qkv shape {tuple(qkv.shape)} != {(B * T, 3 * NH * H)}")
     out = torch.empty((B * T, NH * H), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, NH, T), dtype=torch.float32, device=qkv.device)
+    kb = None
+    if keep and p > 0.0 and rng_state is not None:
+        n = int(lib.dg_attn_keep_bits_bytes(B, T, NH, H, dt_code(qkv.dtype)))
+        if n > 0:
+            kb = torch.empty(n, dtype=torch.uint8, device=qkv.device)
     check(lib.dg_attn_fwd(_p(qkv), _p(out), _p(lse), B, T, NH, H, float(scale), float(p), _p(rng_state) if p > 0.0 else None,
-                          site, dt_code(qkv.dtype), _stream()), "dg_attn_fwd")
+                          site, dt_code(qkv.dtype), _p(kb), kb.numel() if kb is not None else 0, _stream()), "dg_attn_fwd")
+    if kb is not None:
+        out.dg_keep = kb
     return out, lse
 
 
 def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, T: int, NH: int, H: int, scale: float, p: float,
-             rng_state: Optional[Tensor], site: int) -> Tensor:
+             rng_state: Optional[Tensor], site: int, keep_bits: Optional[Tensor] = None) -> Tensor:
+    """keep_bits: the forward pass's keep masks (attn_fwd(..., keep=True) leaves them as out.dg_keep); default: taken from `out`"""
     _chk(qkv, "qkv")
+    if keep_bits is None:
+        keep_bits = getattr(out, "dg_keep", None)
+    if keep_bits is not None:
+        _chk(keep_bits, "keep_bits", torch.uint8)
     _chk(out, "out", qkv.dtype)
     _chk(dout, "dout", qkv.dtype)
     _chk(lse, "lse", torch.float32)
     dqkv = torch.empty_like(qkv)
     ws = torch.empty(int(lib.dg_attn_bwd_workspace_bytes(B, T, NH, H, dt_code(qkv.dtype))), dtype=torch.uint8, device=qkv.device)
     check(lib.dg_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(ws), ws.numel(), B, T, NH, H, float(scale), float(p),
-                          _p(rng_state) if p > 0.0 else None, site, dt_code(qkv.dtype), _stream()), "dg_attn_bwd")
+                          _p(rng_state) if p > 0.0 else None, site, dt_code(qkv.dtype), _p(keep_bits),
+                          keep_bits.numel() if keep_bits is not None else 0, _stream()), "dg_attn_bwd")
     return dqkv
 
 

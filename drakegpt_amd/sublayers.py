@@ -300,7 +300,7 @@ def attn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tenso
     else:
         h, mean, rstd = _as_act(run, x2d), None, None
     qkv = linear_nt(run, h, wqkv, run.act, fp8_site=f"{layer}.h1")
-    o, lse = ops.attn_fwd(qkv, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer))
+    o, lse = ops.attn_fwd(qkv, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer), keep=True)     # (keep masks: only with dropout on)
     if wproj is not None:
         if fuse_ln is not None and nxt is not None and residual and o.shape[1] == x2d.shape[1] and _chain_ok(run, x2d, wproj):
             r = ops.block_chain_fwd(3, x2d.shape[0], x2d.shape[1], o=o, x=x2d, wproj=run.weights.pack(wproj), bproj=bproj, ln2w=fuse_ln[0],

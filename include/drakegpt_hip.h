@@ -45,7 +45,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 16   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 17   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -287,9 +287,14 @@ int dg_transpose_cast_batched(const int64_t* desc, int n_desc, int total_tiles, 
  * qkv: [B*T, 3*NH*H] with column blocks [Q heads | K heads | V heads]; out: [B*T, NH*H], head h
  * at columns h*H.. (the torch.cat of :453 disappears).  lse [B,NH,T] = log-sum-exp of the scaled
  * masked scores, saved for backward.  Dropout element index = ((b*NH+h)*T+i)*T+j. */
+/* keep_bits (nullable; round 3): dg_attn_keep_bits_bytes(...) bytes in which the forward pass leaves its dropout keep decisions
+ * (16 wave masks per unmasked 32 x 32 tile, opaque layout); handed to dg_attn_bwd the dQ pass selects with them instead of
+ * hashing every score again (same decisions either way: the masks are the hash's compare results).  0 bytes = the shape takes
+ * the generic kernels, which have no such path: pass NULL. */
+int64_t dg_attn_keep_bits_bytes(int B, int T, int NH, int H, int dtype);
 int dg_attn_fwd(const void* qkv, void* out, float* lse, int B, int T, int NH, int H,
                 float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
-                int dtype, void* stream);
+                int dtype, void* keep_bits, int64_t keep_bits_bytes, void* stream);
 /* dqkv [B*T, 3*NH*H] from dout.  workspace: at least B*NH*T floats (delta = rowsum(dO * O)); with
  * dg_attn_bwd_workspace_bytes(...) bytes the dQ pass also leaves the dropped-out probabilities and dS of every
  * unmasked 32 x 32 tile behind it and the dK/dV pass consumes them instead of recomputing scores, exp and the
@@ -298,7 +303,7 @@ int64_t dg_attn_bwd_workspace_bytes(int B, int T, int NH, int H, int dtype);
 int dg_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                 void* dqkv, void* workspace, int64_t workspace_bytes, int B, int T, int NH, int H,
                 float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
-                int dtype, void* stream);
+                int dtype, const void* keep_bits, int64_t keep_bits_bytes, void* stream);
 
 /* Single-query attention against a K/V cache for generate() -- ref: src/model.py:625-635 re-runs the
  * whole forward per new token; with the cache only the new position is computed.  qkv_cache:

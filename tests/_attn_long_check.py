@@ -55,7 +55,7 @@ def check_case(dev, B, T, NH, H, p):
     qd = qkv.double().requires_grad_(True)
     ref = attn_ref(qd, B, T, NH, H, keep, p)
     ref.backward(dout.double())
-    out, lse = ops.attn_fwd(qkv.to(dev), B, T, NH, H, H ** -0.5, p, rng, site)
+    out, lse = ops.attn_fwd(qkv.to(dev), B, T, NH, H, H ** -0.5, p, rng, site, keep=os.environ.get("DG_ATTN_KEEPBITS", "1") != "0")
     dqkv = ops.attn_bwd(qkv.to(dev), out, dout.to(dev), lse, B, T, NH, H, H ** -0.5, p, rng, site)
     torch.cuda.synchronize()
     ef, eb = rel(out, ref.detach()), rel(dqkv, qd.grad)

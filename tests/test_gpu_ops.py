@@ -475,7 +475,8 @@ def _attn_ref(qkv, B, T, NH, H, keep=None, p=0.0):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,T,NH,H,p", [(2, 8, 4, 8, 0.0), (3, 37, 2, 16, 0.1), (2, 256, 3, 64, 0.2), (1, 1, 1, 32, 0.0), (2, 130, 2, 64, 0.0)])
+@pytest.mark.parametrize("B,T,NH,H,p", [(2, 8, 4, 8, 0.0), (3, 37, 2, 16, 0.1), (2, 256, 3, 64, 0.2), (1, 1, 1, 32, 0.0), (2, 130, 2, 64, 0.0),
+                                        (3, 100, 2, 64, 0.3)])
 def test_attention(dev, dtype, B, T, NH, H, p):
     from oracle import rng_ref
     ops = _ops()
@@ -499,6 +500,22 @@ def test_attention(dev, dtype, B, T, NH, H, p):
     # backward consumes the kernel's own (rounded) forward output: compare against fp64 grads
     tolg = 3e-5 if dtype == torch.float32 else 2e-2
     assert rel(dqkv, qd.grad) < tolg, rel(dqkv, qd.grad)
+    # round 3: the forward pass can leave its keep decisions as wave masks and the dQ pass then selects with them instead of hashing
+    # again -- the same decisions, hence the same output and the same gradient bit for bit (shapes on the generic kernels: no masks)
+    out_k, lse_k = ops.attn_fwd(qkv.to(dev), B, T, NH, H, H ** -0.5, p, rng, site, keep=True)
+    has = getattr(out_k, "dg_keep", None) is not None
+    assert has == (p > 0 and dtype == torch.bfloat16 and H == 64)
+    # (the two template instances contract their fp32 expressions differently: an ulp of lse, never a decision)
+    assert torch.equal(out_k, out) and rel(lse_k, lse) < 1e-6
+    if has:
+        assert out_k.dg_keep.numel() == B * NH * (((T + 31) // 32) * ((T + 31) // 32 + 1) // 2) * 128
+        dqkv_k = ops.attn_bwd(qkv.to(dev), out, dout.to(dev), lse, B, T, NH, H, H ** -0.5, p, rng, site, keep_bits=out_k.dg_keep)
+        a, b = dqkv_k.float(), dqkv.float()
+        # a wrong keep decision moves an element by many bf16 ulps; contraction differences by one at most
+        assert bool(((a - b).abs() <= 2.0 ** -6 * torch.maximum(a.abs(), b.abs()) + 1e-6 * b.abs().max()).all())
+        assert rel(a, b) < 2e-4, rel(a, b)
+        with pytest.raises(RuntimeError):                      # a record buffer that is too small is rejected before the launch
+            ops.attn_bwd(qkv.to(dev), out, dout.to(dev), lse, B, T, NH, H, H ** -0.5, p, rng, site, keep_bits=out_k.dg_keep[:-128])
 
 
 def test_cross_entropy_and_reduce(dev):
@@ -766,7 +783,7 @@ def test_argument_validation_rejects_before_launch(dev):
     assert lib.dg_gemm_nt(C.byref(a), None) == -3                    # DG_ERR_DTYPE
     a.in_dtype, a.M = _lib.DG_F32, 0
     assert lib.dg_gemm_nt(C.byref(a), None) == -1                    # DG_ERR_ARG
-    assert lib.dg_attn_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 8, 1, 300, 1.0, 0.0, None, 0, _lib.DG_F32, None) == -1
+    assert lib.dg_attn_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 8, 1, 300, 1.0, 0.0, None, 0, _lib.DG_F32, None, 0, None) == -1
     assert lib.dg_layernorm_fwd(None, x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, x.data_ptr(), x.data_ptr(), 4, 40, 1e-5, None) == -1
     with pytest.raises(RuntimeError, match="invalid argument"):
         _lib.check(-1, "probe")
