@@ -67,6 +67,19 @@ __device__ __forceinline__ void attn_item(const AttnP& p, int wave, int64_t& bh,
         return;
     }
     const int wpq = p.nblk >> 2;                       // workgroups per (batch, head)
+    if (p.balance == 2) {
+        // More workgroups than the chip holds at once (round 3: GPT-2-medium at B = 8 is 1 024 workgroups on 768 slots): with
+        // equal-cost workgroups the last third of them runs alone at one workgroup per CU -- a whole second round at a quarter of
+        // the occupancy (dQ 184 us where 1.33 full rounds would be ~147).  Heavy first instead: class k = the four blocks
+        // 4k .. 4k + 3 from the heavy end, all (batch, head) pairs of class 0 before any of class 1, so the light classes fill the
+        // tail.  blockIdx % 8 == bh % 8 for B * NH % 8 == 0: a pair's workgroups still share one XCD's L2.
+        const int n_bh = p.B * p.NH;
+        const int cls = (int)blockIdx.x / n_bh;
+        bh = (int)blockIdx.x % n_bh;
+        valid = cls < wpq;
+        blk = p.nblk - 1 - (4 * cls + wave);           // callers: qb = blk (heavy = late queries), kb = nblk - 1 - blk (heavy = early keys)
+        return;
+    }
     // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8, a speed assumption only), each with its own L2.  The
     // remap gives XCD k a contiguous range of (batch, head) pairs, so the wpq workgroups of one pair share K / V (Q / dO
     // in the dK/dV pass) through one L2 instead of fetching them wpq times: backward 62.6 -> 58.4 us per layer.
@@ -977,13 +990,16 @@ static void fill(AttnP& p, int B, int T, int NH, float scale, float dp, const ui
     p.inv_keep = 1.f / (1.f - dp);
     p.thr = dg_drop_threshold(dp);
     p.rng = rng; p.site = site;
-    static const int mode = [] { const char* e = getenv("DG_ATTN_BALANCE"); return e ? atoi(e) : 1; }();   // 0 = plain order (A/B runs)
+    static const int mode = [] { const char* e = getenv("DG_ATTN_BALANCE"); return e ? atoi(e) : 2; }();   // 0 = plain order, 1 = equal-cost workgroups always, 2 (default) = equal-cost for one residency, heavy first beyond
     static const int ncu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
     p.balance = (mode != 0 && p.nblk % 4 == 0) ? 1 : 0;
+    // heavy-first order when the launch is more than one residency (three 256-thread workgroups per CU); DG_ATTN_BALANCE=1 keeps the
+    // equal-cost order everywhere (A/B)
+    if (p.balance && mode != 1 && (int64_t)B * NH * (p.nblk / 4) > (int64_t)3 * ncu * 11 / 10) p.balance = 2;
     p.rot_div = ncu;
     static const int xcd = [] { const char* e = getenv("DG_ATTN_XCD"); return e ? atoi(e) : 1; }();   // 0 = plain blockIdx order (A/B runs)
     p.xcd = xcd;
