@@ -48,6 +48,31 @@ extern "C" int dg_fp8_amax(const void* x, int dtype, int64_t n, const int64_t* s
     return DG_OK;
 }
 
+// eight fp32 values -> eight fp8 bytes (two dwords), saturating at fmax after the scale
+template <bool BF8>
+__device__ __forceinline__ void fp8_pack8(const float (&v)[8], int& lo, int& hi) {
+    lo = 0; hi = 0;
+    if (BF8) {
+        lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], lo, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_bf8_f32(v[4], v[5], hi, false); hi = __builtin_amdgcn_cvt_pk_bf8_f32(v[6], v[7], hi, true);
+    } else {
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void fp8_load8(const T* p, float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        const bf16x8 t = *(const bf16x8*)p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+    } else {
+        const f32x4 t0 = *(const f32x4*)p, t1 = *(const f32x4*)(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[4 + e] = t1[e]; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // q = cvt(clamp(x * scale)), scale = FMAX / amax (amax == 0: scale 1); scale_inv[seg] = 1 / scale is written by block 0 of
 // the segment for the consumer.  Eight elements per thread: 16 B in (bf16) / 2 x 16 B (f32), 8 B out.
@@ -69,29 +94,35 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__
     am = dg_amax_nan(dg_amax_nan(red[0], red[1]), dg_amax_nan(red[2], red[3]));
     const float sc = dg_fp8_scale_of(am, fmax);
     if (b == 0 && threadIdx.x == 0 && scale_inv) scale_inv[s] = 1.f / sc;
+    // Sixteen elements per thread and trip where the segment allows it (start and length multiples of 16: every weight matrix):
+    // ONE 16-byte store per lane instead of two 8-byte ones -- 8-byte stores run at half the rate of 16-byte ones on this part
+    // (DESIGN section 4), and this kernel sat at 1.6 TB/s.  Odd chunk counts and unaligned segments keep the 8-element form.
     const int64_t n8 = len / 8;
+    const bool wide = ((first | len) & 15) == 0 && ((((uintptr_t)(q + first)) & 15) == 0) && ((((uintptr_t)(x + first)) & 15) == 0);
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    if (wide) {
+        const int64_t n16 = len / 16;
+        for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < n16; i += (int64_t)nb * 256) {
+            float v0[8], v1[8];
+            fp8_load8<T>(x + first + i * 16, v0);
+            fp8_load8<T>(x + first + i * 16 + 8, v1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v0[e] = dg_fp8_clamp(v0[e] * sc, fmax); v1[e] = dg_fp8_clamp(v1[e] * sc, fmax); }
+            int a, bq, c, d;
+            fp8_pack8<BF8>(v0, a, bq);
+            fp8_pack8<BF8>(v1, c, d);
+            *(i32x4*)(q + first + i * 16) = (i32x4){a, bq, c, d};
+        }
+        return;
+    }
     for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < n8; i += (int64_t)nb * 256) {
         float v[8];
-        if constexpr (sizeof(T) == 2) {
-            const bf16x8 t = *(const bf16x8*)(x + first + i * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
-        } else {
-            const f32x4 t0 = *(const f32x4*)(x + first + i * 8), t1 = *(const f32x4*)(x + first + i * 8 + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[4 + e] = t1[e]; }
-        }
+        fp8_load8<T>(x + first + i * 8, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = dg_fp8_clamp(v[e] * sc, fmax);
-        int lo = 0, hi = 0;
-        if (BF8) {
-            lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], lo, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], lo, true);
-            hi = __builtin_amdgcn_cvt_pk_bf8_f32(v[4], v[5], hi, false); hi = __builtin_amdgcn_cvt_pk_bf8_f32(v[6], v[7], hi, true);
-        } else {
-            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
-            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
-        }
-        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        int lo, hi;
+        fp8_pack8<BF8>(v, lo, hi);
         *(i32x2*)(q + first + i * 8) = (i32x2){lo, hi};
     }
 }
@@ -148,29 +179,36 @@ __global__ __launch_bounds__(1024) void fp8_quantize_delayed_kernel(const T* __r
     if (blockIdx.x == 0 && threadIdx.x == 0) scale_inv[0] = 1.f / sc;
     float m = 0.f;
     const int64_t n8 = n / 8;
-    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n8; i += (int64_t)DG_FP8_AMAX_PARTS * 1024) {
-        float v[8];
-        if constexpr (sizeof(T) == 2) {
-            const bf16x8 t = *(const bf16x8*)(x + i * 8);
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    // sixteen elements per thread and trip (one 16-byte store per lane, see fp8_quantize_kernel) when n and the pointers allow it
+    const bool wide = (n & 15) == 0 && ((((uintptr_t)q) & 15) == 0) && ((((uintptr_t)x) & 15) == 0);
+    if (wide) {
+        const int64_t n16 = n / 16;
+        for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n16; i += (int64_t)DG_FP8_AMAX_PARTS * 1024) {
+            float v0[8], v1[8];
+            fp8_load8<T>(x + i * 16, v0);
+            fp8_load8<T>(x + i * 16 + 8, v1);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
-        } else {
-            const f32x4 t0 = *(const f32x4*)(x + i * 8), t1 = *(const f32x4*)(x + i * 8 + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[4 + e] = t1[e]; }
+            for (int e = 0; e < 8; ++e) {
+                m = dg_amax_nan(m, v0[e]); m = dg_amax_nan(m, v1[e]);
+                v0[e] = dg_fp8_clamp(v0[e] * sc, fmax); v1[e] = dg_fp8_clamp(v1[e] * sc, fmax);
+            }
+            int a, b, c, d;
+            fp8_pack8<BF8>(v0, a, b);
+            fp8_pack8<BF8>(v1, c, d);
+            *(i32x4*)(q + i * 16) = (i32x4){a, b, c, d};
         }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n8; i += (int64_t)DG_FP8_AMAX_PARTS * 1024) {
+            float v[8];
+            fp8_load8<T>(x + i * 8, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { m = dg_amax_nan(m, v[e]); v[e] = dg_fp8_clamp(v[e] * sc, fmax); }
-        int lo = 0, hi = 0;
-        if (BF8) {
-            lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], lo, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], lo, true);
-            hi = __builtin_amdgcn_cvt_pk_bf8_f32(v[4], v[5], hi, false); hi = __builtin_amdgcn_cvt_pk_bf8_f32(v[6], v[7], hi, true);
-        } else {
-            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
-            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+            for (int e = 0; e < 8; ++e) { m = dg_amax_nan(m, v[e]); v[e] = dg_fp8_clamp(v[e] * sc, fmax); }
+            int lo, hi;
+            fp8_pack8<BF8>(v, lo, hi);
+            *(i32x2*)(q + i * 8) = (i32x2){lo, hi};
         }
-        typedef int i32x2 __attribute__((ext_vector_type(2)));
-        *(i32x2*)(q + i * 8) = (i32x2){lo, hi};
     }
     m = wave_amax_nan(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
