@@ -18,7 +18,7 @@ DG_F32 = 0
 DG_BF16 = 1
 DG_FP8_E4M3 = 2
 DG_FP8_E5M2 = 3
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class GemmNtArgs(C.Structure):
@@ -49,6 +49,7 @@ class GemmNtArgs(C.Structure):
         ("fp8_out_parts2", C.c_void_p),
         ("fp8_out_step", C.c_void_p),
         ("fp8_out_scale_inv", C.c_void_p),
+        ("fp8_out_only", C.c_int32),
     ]
 
 
@@ -109,7 +110,7 @@ SIGNATURES = {
     "dg_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp],
     "dg_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "dg_layernorm_bwd_fused": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _vp, _u32, _vp, _vp],
-    "dg_layernorm_bwd_fused_fp8": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "dg_layernorm_bwd_fused_fp8": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "dg_gemm_nt": [C.POINTER(GemmNtArgs), _vp],
     "dg_gemm_nt_sign_bits_supported": [C.POINTER(GemmNtArgs)],
     "dg_gemm_nt_fp8_out_supported": [C.POINTER(GemmNtArgs)],

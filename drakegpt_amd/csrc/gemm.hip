@@ -298,6 +298,7 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
     NtParams p;
     p.q8 = (unsigned char*)a->fp8_out; p.ldq8 = a->ld_fp8_out; p.q_parts2 = a->fp8_out_parts2; p.q_step = a->fp8_out_step;
     p.q_scale_inv = a->fp8_out_scale_inv;
+    p.q8_only = (a->fp8_out && a->fp8_out_only) ? 1 : 0;
     p.A = (const char*)a->A; p.lda_b = a->lda * esz;
     p.B = (const char*)a->B; p.ldb_b = a->ldb * esz;
     p.C = a->C; p.ldc = a->ldc;

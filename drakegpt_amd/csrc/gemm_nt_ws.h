@@ -61,6 +61,7 @@ struct NtParams {
     int res_prefetch;             // EPI 3 / 7: loader waves touch the residual tile ahead of the epilogue (DG_NT_RESPF, default 0: measured slower)
     // EPI 8: the output is ALSO written as e4m3 (the next GEMM's fp8 operand) with delayed per-tensor scaling
     unsigned char* q8; int64_t ldq8;          // [M][ldq8] bytes
+    int q8_only;                              // EPI 8 / 9: C is not written (nobody reads the bf16 form: fp8 consumers only)
     float* q_parts2;                          // [2][256] partial maxima of the call site (dg_fp8_quantize_delayed's layout)
     const uint32_t* q_step;                   // device step word: slot (step & 1) is written, the other one read
     float* q_scale_inv;                       // [1]: dequantisation factor for the consumer
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
                 if constexpr (sizeof(TO) == 4) {
                     *(f32x4*)cp = (f32x4){v[0], v[1], v[2], v[3]};
                     *(f32x4*)(cp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                } else {
+                } else if (!(QOUT && p.q8_only)) {              // (uniform)
                     bf16x8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];

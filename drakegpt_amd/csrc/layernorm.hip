@@ -122,6 +122,7 @@ struct LnFuse {
     // fp8 mode (nullable): g a second time as e5m2 with delayed scaling -- the operand of the dX GEMM that runs next -- in
     // dg_fp8_quantize_delayed's protocol: the launch has exactly 256 workgroups, each leaves ONE partial maximum (plain store)
     unsigned char* g8; float* q_parts2; const uint32_t* q_step; float* q_scale_inv;
+    int g8_only;      // (with g8) the bf16 form of g is not written: its consumers -- the dX GEMM and the grouped dW launch -- read the e5m2 copy
 };
 // TR: type of the residual-branch gradient stream (dresid in, dx out): float, or bf16 on the vector path -- the engine's bf16 /
 // fp8 modes keep the stream in bf16 (it is rounded once per sub-layer, like every other activation gradient of those modes):
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(NTHREADS) void ln_bwd_kernel(LnFuse fz, const TD* _
                             bf16x4 t;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) t[j] = (bf16_t)gq[j];
-                            *(bf16x4*)((bf16_t*)fz.g + (int64_t)row * C + i * 4) = t;
+                            if (!fz.g8_only) *(bf16x4*)((bf16_t*)fz.g + (int64_t)row * C + i * 4) = t;       // (uniform)
                             if (fz.g8) {                // (uniform)
                                 float w4[4];
 #pragma unroll
@@ -424,7 +425,7 @@ extern "C" int dg_layernorm_bwd_fused(const void* dy, int dy_dtype, const float*
     fz.inv_keep = 1.f / (1.f - dropout_p);
     fz.thr = dg_drop_threshold(dropout_p);
     fz.rng = rng_state; fz.site = site;
-    fz.g8 = nullptr; fz.q_parts2 = nullptr; fz.q_step = nullptr; fz.q_scale_inv = nullptr;
+    fz.g8 = nullptr; fz.q_parts2 = nullptr; fz.q_step = nullptr; fz.q_scale_inv = nullptr; fz.g8_only = 0;
     return ln_bwd_launch(fz, g_dtype == DG_BF16 ? 1 : 2, dy, dy_dtype, x, gamma, mean, rstd, dresid, dx, resid_dtype, dgamma_part, dbeta_part,
                          part_stride, n_partials, M, C, stream);
 }
@@ -434,7 +435,7 @@ extern "C" int dg_layernorm_bwd_fused_fp8(const void* dy, int dy_dtype, const fl
                                           float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
                                           int M, int C,
                                           void* g, float dropout_p, const uint32_t* rng_state, uint32_t site, float* gbias_part,
-                                          void* g8, float* g8_parts2, const uint32_t* step_state, float* g8_scale_inv, void* stream) {
+                                          void* g8, float* g8_parts2, const uint32_t* step_state, float* g8_scale_inv, int g8_only, void* stream) {
     if (dropout_p < 0.f || dropout_p >= 1.f) return DG_ERR_ARG;
     if (!g8 || !g8_parts2 || !step_state || !g8_scale_inv || n_partials != DG_FP8_AMAX_PARTS || C % 4 || (((uintptr_t)g8) & 3)) return DG_ERR_ARG;
     LnFuse fz;
@@ -444,6 +445,7 @@ extern "C" int dg_layernorm_bwd_fused_fp8(const void* dy, int dy_dtype, const fl
     fz.thr = dg_drop_threshold(dropout_p);
     fz.rng = rng_state; fz.site = site;
     fz.g8 = (unsigned char*)g8; fz.q_parts2 = g8_parts2; fz.q_step = step_state; fz.q_scale_inv = g8_scale_inv;
+    fz.g8_only = g8_only ? 1 : 0;
     return ln_bwd_launch(fz, 1, dy, dy_dtype, x, gamma, mean, rstd, dresid, dx, resid_dtype, dgamma_part, dbeta_part,
                          part_stride, n_partials, M, C, stream);
 }

@@ -119,6 +119,8 @@ class FlatSink:
                         and x8[0].shape == (x.shape[0], Q) and ops._ld(d8[0]) % 16 == 0 and ops._ld(x8[0]) % 16 == 0):
                     f8.append((d8[0], x8[0], view, P, Q, d8[1], x8[1]))
                 else:
+                    S._refuse_unwritten(dy)
+                    S._refuse_unwritten(x)
                     bf.append((dy, x, view, P, Q))
             for kind, probs in ((0, bf), (1, f8)):
                 if not probs:
@@ -763,7 +765,8 @@ class TrainEngine:
         if seed:
             self._fp8_seeded = True
         return S.Run(act=self.act, rng=self.state if self.p_drop > 0.0 else None, weights=self.weights, fp8=self.fp8,
-                     fp8_sites=self.fp8_sites if self.fp8 else None, fp8_seed=seed, step_word=self.state, stream=self.stream_dtype)
+                     fp8_sites=self.fp8_sites if self.fp8 else None, fp8_seed=seed, step_word=self.state, stream=self.stream_dtype,
+                     fp8_only=self.fp8 and self.fp8_dw and self.grouped_dw and _os_env("DG_FP8_ONLY", "1") != "0")
 
     def _prog_fwd_bwd(self):
         """gather the batch, forward, backward, reduce the gradient partials"""

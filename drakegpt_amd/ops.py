@@ -188,7 +188,7 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
 def layernorm_bwd_fused(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dresid: Optional[Tensor],
                         dgamma_part: Tensor, dbeta_part: Tensor, part_stride: int, n_partials: int,
                         g_dtype: torch.dtype, p: float, rng_state: Optional[Tensor], site: int, gbias_part: Optional[Tensor],
-                        stream_dtype: torch.dtype = torch.float32, fp8_out=None):
+                        stream_dtype: torch.dtype = torch.float32, fp8_out=None, fp8_out_only: bool = False):
     """layernorm_bwd that also emits g = dropout_bwd(dx) in g_dtype and its column-sum partials; returns (dx, g).
     stream_dtype: type of dresid (in) and dx (out), fp32 or bf16 (the engine's bf16 gradient stream: bf16 dy and g only).
     fp8_out = (parts2 fp32 [2 * FP8_AMAX_PARTS], step_state): g (bf16) also leaves as e5m2 with delayed scaling -- the operand of
@@ -212,7 +212,9 @@ def layernorm_bwd_fused(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd
         check(lib.dg_layernorm_bwd_fused_fp8(_p(dy), dt_code(dy.dtype), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dresid), _p(dx), dt_code(stream_dtype),
                                              _p(dgamma_part), _p(dbeta_part), part_stride, n_partials, M, Cd, _p(g), float(p),
                                              _p(rng_state) if p > 0.0 else None, site, _p(gbias_part), _p(g8), _p(parts2), _p(step_state), _p(sinv),
-                                             _stream()), "dg_layernorm_bwd_fused_fp8")
+                                             1 if fp8_out_only else 0, _stream()), "dg_layernorm_bwd_fused_fp8")
+        if fp8_out_only:
+            g.dg_unwritten = True           # (its consumers read g8)
         return dx, g, g8, sinv
     check(lib.dg_layernorm_bwd_fused(_p(dy), dt_code(dy.dtype), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dresid), _p(dx), dt_code(stream_dtype), _p(dgamma_part),
                                      _p(dbeta_part), part_stride, n_partials, M, Cd, _p(g), dt_code(g_dtype), float(p),
@@ -229,8 +231,9 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
             residual: Optional[Tensor] = None, dropout_p: float = 0.0, rng_state: Optional[Tensor] = None,
             site: int = 0, out: Optional[Tensor] = None, sign_bits_out: Optional[Tensor] = None,
             sign_bits: Optional[Tensor] = None, colsum_part: Optional[Tensor] = None,
-            scale_a: Optional[Tensor] = None, scale_b: Optional[Tensor] = None, fp8_out=None) -> Tensor:
+            scale_a: Optional[Tensor] = None, scale_b: Optional[Tensor] = None, fp8_out=None, fp8_out_only: bool = False) -> Tensor:
     """out[M,N] = epilogue(A[M,K] @ Bm[N,K]^T).  A/Bm may carry padding columns beyond K (ld > K).
+    fp8_out_only: with fp8_out, do not write `out` (nobody reads the bf16 form); the returned tensor is marked dg_unwritten.
     fp8_out: (q8 [M, N] float8_e4m3fn -- float8_e5m2 in the dX direction --, parts2 fp32 [2 * FP8_AMAX_PARTS], step_state, scale_inv fp32 [1]) -- the epilogue also
     writes the output as e4m3 with delayed scaling (what fp8_quantize_delayed would make of it); only where
     gemm_nt_fp8_out_supported(M, N, K).
@@ -297,6 +300,13 @@ def gemm_nt(A: Tensor, Bm: Tensor, out_dtype: torch.dtype, *, N: Optional[int] =
             raise RuntimeError("gemm_nt: fp8_out must be [M, N] with a [2 * FP8_AMAX_PARTS] history")
         a.fp8_out, a.ld_fp8_out = _p(q8), _ld(q8)
         a.fp8_out_parts2, a.fp8_out_step, a.fp8_out_scale_inv = _p(parts2), _p(step_state), _p(q_scale_inv)
+        if fp8_out_only:
+            # the bf16 form stays unwritten (the tensor is returned as the carrier of the fp8 copy's attributes only); a consumer
+            # that would read it must refuse: dg_unwritten marks it
+            a.fp8_out_only = 1
+            out.dg_unwritten = True
+    elif fp8_out_only:
+        raise RuntimeError("gemm_nt: fp8_out_only needs fp8_out")
     check(lib.dg_gemm_nt(C.byref(a), _stream()), "dg_gemm_nt")
     return out
 

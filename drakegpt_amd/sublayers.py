@@ -170,6 +170,8 @@ class Run:
     fp8_seed: bool = False           # engine warm-up: quantise just in time and seed the sites' history with this batch's amax
     step_word: Optional[Tensor] = None   # device {seed, step} words: the step parity selects the history slot
     stream: torch.dtype = torch.float32  # type of the residual-branch gradient stream (engine, bf16 / fp8 modes: bf16)
+    fp8_only: bool = False               # engine, precision fp8 with the fp8 dW: the FFN hidden layer and its gradient are read as fp8
+                                         # only (by the next GEMM and by the grouped dW launch), so their bf16 form is not written
 
     def p(self, p: float) -> float:
         return p if (self.rng is not None and p > 0.0) else 0.0
@@ -196,6 +198,12 @@ def _quantize_operand(run: Run, x: Tensor, fmt: torch.dtype, site: Optional[str]
     return ops.fp8_quantize_delayed(x, fmt, parts2, run.step_word)
 
 
+def _refuse_unwritten(t: Tensor) -> None:
+    """a tensor whose bf16 form was skipped (gemm_nt fp8_out_only) must never be read as bf16"""
+    if getattr(t, "dg_unwritten", False):
+        raise RuntimeError("drakegpt_amd: this operand exists as fp8 only (fp8_out_only) and a bf16 consumer asked for it")
+
+
 def linear_nt(run: Run, x: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: Optional[str] = None, x8=None, **epi) -> Tensor:
     """forward of a block Linear: epilogue(x W^T), x [M, in] in the activation dtype, W [out, in] the fp32 master.
     fp8 mode: x is quantised to e4m3 (see _quantize_operand) -- or arrives quantised already as x8 = (e4m3 copy, scale) from
@@ -205,6 +213,7 @@ def linear_nt(run: Run, x: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: 
         xq, xs = x8 if x8 is not None else _quantize_operand(run, x, E4M3, fp8_site)
         x.dg_fp8x = (xq, xs)        # the e4m3 copy travels with the activation: it is also the X operand of this Linear's fp8 dW
         return ops.gemm_nt(xq, wq, out_dtype, scale_a=xs, scale_b=ws, **epi)
+    _refuse_unwritten(x)
     return ops.gemm_nt(x, run.weights.fwd(W), out_dtype, **epi)
 
 
@@ -231,6 +240,7 @@ def linear_dx(run: Run, g: Tensor, W: Tensor, out_dtype: torch.dtype, fp8_site: 
             gq, gs = g8 if g8 is not None else _quantize_operand(run, g, E5M2, fp8_site)
             g.dg_fp8 = (gq, gs)     # (also the dY operand of this Linear's fp8 dW, looked up when the grouped launch is assembled)
             return ops.gemm_nt(gq, wq, out_dtype, K=K, scale_a=gs, scale_b=ws, **epi)
+    _refuse_unwritten(g)
     return ops.gemm_nt(g, run.weights.bwd(W), out_dtype, K=K, **epi)
 
 
@@ -266,7 +276,8 @@ def _ln_tail(run: Run, dh: Tensor, x2d: Tensor, ln_w: Tensor, mean, rstd, dresid
         if (f8site is not None and run.fp8 and run.fp8_sites is not None and not run.fp8_seed and f8site in run.fp8_sites
                 and run.step_word is not None and run.act == torch.bfloat16 and ng == ops.FP8_AMAX_PARTS and fp8_k_ok(N) and FUSED_LN_FP8):
             dx, g, g8, gs = ops.layernorm_bwd_fused(dh, x2d, ln_w, mean, rstd, dresid, pg, pb, sg, ng, run.act, run.p(p), run.rng, site, pq,
-                                                    stream_dtype=run.stream, fp8_out=(run.fp8_sites[f8site], run.step_word))
+                                                    stream_dtype=run.stream, fp8_out=(run.fp8_sites[f8site], run.step_word),
+                                                    fp8_out_only=run.fp8_only)
             g.dg_fp8 = (g8, gs)
             return dx, g
         return ops.layernorm_bwd_fused(dh, x2d, ln_w, mean, rstd, dresid, pg, pb, sg, ng, run.act, run.p(p), run.rng, site, pq,
@@ -371,7 +382,8 @@ def ffn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor
             and ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w2.shape[0], in_dtype=_op_dtype(run, w2.shape[0], grad=True))):
         bits = ops.new_sign_bits(h.shape[0], w1.shape[0], h.device)
     f8 = _fused_fp8_out(run, f"{layer}.f", h.shape[0], w1.shape[0], w1.shape[1], h.device) if bits is not None else None
-    f = linear_nt(run, h, w1, run.act, fp8_site=f"{layer}.h2", bias=b1, relu=True, sign_bits_out=bits, fp8_out=f8)
+    f = linear_nt(run, h, w1, run.act, fp8_site=f"{layer}.h2", bias=b1, relu=True, sign_bits_out=bits, fp8_out=f8,
+                  fp8_out_only=bool(f8 is not None and run.fp8_only and w2 is not None))
     if (fuse_ln is not None and nxt is not None and residual and out_dtype == torch.float32 and w1.shape[0] == 4 * x2d.shape[1]
             and _chain_ok(run, x2d, w2)):
         r = ops.block_chain_fwd(4, x2d.shape[0], x2d.shape[1], f=f, x1=x2d, w2=run.weights.pack(w2), b2=b2, ln1w=fuse_ln[0], ln1b=fuse_ln[1],
@@ -411,7 +423,8 @@ def ffn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], w1: Tensor, w2:
             # second time as the e5m2 operand of the first Linear's dX GEMM below
             if need_dx:
                 df8 = _fused_fp8_out(run, f"{layer}.df", g.shape[0], w1.shape[0], w2.shape[0], g.device, grad=True)
-            df = linear_dx(run, g, w2, run.act, fp8_site=f"{layer}.g_ffn", sign_bits=bits, colsum_part=cs_part, fp8_out=df8)
+            df = linear_dx(run, g, w2, run.act, fp8_site=f"{layer}.g_ffn", sign_bits=bits, colsum_part=cs_part, fp8_out=df8,
+                           fp8_out_only=bool(df8 is not None and run.fp8_only and ln_w is not None))
         else:
             if bits is not None:
                 df = linear_dx(run, g, w2, run.act, fp8_site=f"{layer}.g_ffn", sign_bits=bits)

@@ -45,7 +45,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 17   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 18   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -120,7 +120,8 @@ int dg_layernorm_bwd_fused_fp8(const void* dy, int dy_dtype, const float* x, con
                                float* dgamma_part, float* dbeta_part, int64_t part_stride, int n_partials,
                                int M, int C,
                                void* g, float dropout_p, const uint32_t* rng_state, uint32_t site, float* gbias_part,
-                               void* g8, float* g8_parts2, const uint32_t* step_state, float* g8_scale_inv, void* stream);
+                               void* g8, float* g8_parts2, const uint32_t* step_state, float* g8_scale_inv, int g8_only, void* stream);
+/* g8_only != 0: the bf16 form of g is not written (its consumers read the e5m2 copy); g must still be a valid pointer. */
 
 /* ---------------------------------------------------------------------------------------
  * GEMM "NT": C[M,N] = epilogue(A[M,K] . B[N,K]^T), MFMA with fp32 accumulation.
@@ -175,6 +176,10 @@ typedef struct dg_gemm_nt_args {
     float* fp8_out_parts2;
     const uint32_t* fp8_out_step;
     float* fp8_out_scale_inv;
+    /* fp8_out_only != 0 (with fp8_out): C is NOT written -- the fp8 copy (and the sign bits / column sums) is all the callers of
+     * this output read (the engine's fp8 step: the FFN hidden layer and its gradient feed an fp8 GEMM and the fp8 dW launch only);
+     * C must still be a valid pointer (shape / alignment checks). */
+    int32_t fp8_out_only;
 } dg_gemm_nt_args;
 int dg_gemm_nt(const dg_gemm_nt_args* args, void* stream);
 int dg_gemm_nt_sign_bits_supported(const dg_gemm_nt_args* args);

@@ -662,3 +662,40 @@ def test_fp8_head_engine_step(dev):
     # measured (round 3): loss 1.5e-5, lm_head.weight 2.7e-2, lm_head.bias 3.5e-4, block gradients 6.1e-2 / 6.7e-2 (e5m2 dlogits: 2 mantissa bits)
     assert abs(l1 - l0) < 2e-3 * l0 and e["lm_head.weight"] < 0.1 and e["lm_head.bias"] < 2e-2
     assert e["blocks.0.ffwd.net.2.weight"] < 0.15 and e["blocks.0.sa_head.proj.weight"] < 0.15, e
+
+
+def test_fp8_only_outputs_equal_the_written_ones(dev):
+    """round 3: in precision fp8 with the fp8 dW launch the FFN hidden layer, its gradient and the LayerNorm backward's gradient operand
+    are read as fp8 ONLY (by the next GEMM and by the grouped dW launch), so their bf16 form is not written any more (dg_gemm_nt
+    fp8_out_only, dg_layernorm_bwd_fused_fp8 g8_only).  Same fp8 values either way: three captured steps with and without the stores
+    (DG_FP8_ONLY=0) give the same loss and the same gradient bit for bit; an unwritten tensor refuses a bf16 consumer."""
+    import os
+    import drakegpt_amd as D
+    from drakegpt_amd import sublayers as S
+    from drakegpt_amd.engine import TrainEngine
+    V, C, T, NH, L, B = 80, 384, 256, 6, 2, 8
+    g = torch.Generator().manual_seed(21)
+    xs = [torch.randint(0, V, (B, T), generator=g).to(dev) for _ in range(3)]
+    ys = [torch.randint(0, V, (B, T), generator=g).to(dev) for _ in range(3)]
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["DG_FP8_ONLY"] = mode
+        try:
+            torch.manual_seed(42)
+            m = D.TransformerLM(V, C, T, NH, L, 0.1, precision="fp8").to(dev).train()
+            eng = TrainEngine(m, B, T, lr=1e-3, seed=5, use_graph=True)
+            res = []
+            for x, y in zip(xs, ys):
+                eng.set_batch(x, y)
+                loss = eng.step().item()
+                res.append((loss, torch.cat([v.reshape(-1).float() for v in eng.named_grads().values()]).clone()))
+            eng.check_status()
+        finally:
+            os.environ.pop("DG_FP8_ONLY", None)
+        out[mode] = res
+    for (l1, g1), (l0, g0) in zip(out["1"], out["0"]):
+        assert l1 == l0 and torch.equal(g1, g0)
+    t = torch.zeros(4, 4, device=dev, dtype=torch.bfloat16)
+    t.dg_unwritten = True
+    with pytest.raises(RuntimeError):
+        S._refuse_unwritten(t)
