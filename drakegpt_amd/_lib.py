@@ -108,6 +108,8 @@ SIGNATURES = {
     "dg_batch_embed_fwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp],
     "dg_embed_bwd": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "dg_layernorm_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp],
+    "dg_layernorm_fwd_fp8_parts": [_i],
+    "dg_layernorm_fwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _vp, _vp],
     "dg_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
     "dg_layernorm_bwd_fused": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _vp, _u32, _vp, _vp],
     "dg_layernorm_bwd_fused_fp8": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _i, _i, _vp, _f, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _i, _vp],

@@ -89,6 +89,122 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LayerNorm forward whose output leaves as OCP e4m3 (precision fp8, round 3): y8 = cvt(clamp(y * FMAX / amax_prev)) with the
+// maximum this call site saw one step ago, while the maximum of THIS output is recorded for the next step -- the delayed-scaling
+// protocol of dg_fp8_quantize_delayed with ONE partial maximum per workgroup of this launch (plain stores, no atomics): parts2 =
+// [2][n_parts] floats, n_parts = dg_layernorm_fwd_fp8_parts(M) = the grid; every workgroup reduces the previous slot (n_parts
+// values, L2-resident) itself.  The bf16 form is optional (y == NULL: its only readers, the next GEMM and the grouped dW launch,
+// take the e4m3 copy).  One cast launch and a 2-byte round trip of the activation less per LayerNorm.
+template <int LN_MAXV>
+__global__ __launch_bounds__(256) void ln_fwd_fp8_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         bf16_t* __restrict__ y, unsigned char* __restrict__ q8, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, int M, int C, float eps, float* __restrict__ parts2, int n_parts,
+                                                         const uint32_t* __restrict__ step_word, float* __restrict__ scale_inv) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int row0 = (blockIdx.x * 4 + w) * LN_RPW;
+    const float invC = 1.f / (float)C;
+    const int nv = C >> 2;
+    // the rows are requested first: the history reduction below (n_parts values from L2, two workgroup barriers) runs under their latency
+    f32x4 v[LN_RPW][LN_MAXV];
+#pragma unroll
+    for (int r = 0; r < LN_RPW; ++r) {
+        int row = row0 + r; row = row < M ? row : M - 1;
+        const f32x4* xr = (const f32x4*)(x + (int64_t)row * C);
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            const int i = lane + k * 64;
+            v[r][k] = (i < nv) ? xr[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    f32x4 g[LN_MAXV], b[LN_MAXV];
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int i = lane + k * 64;
+        g[k] = (i < nv) ? ((const f32x4*)gamma)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        b[k] = (i < nv) ? ((const f32x4*)beta)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int parity = (int)(step_word[2] & 1u);
+    const float* prev = parts2 + (int64_t)(parity ^ 1) * n_parts;
+    float* next = parts2 + (int64_t)parity * n_parts;
+    float am = 0.f;
+    for (int i = threadIdx.x; i < n_parts; i += 256) am = dg_amax_nan(am, prev[i]);
+    am = wave_amax_nan(am);
+    if (lane == 0) red[w] = am;
+    __syncthreads();
+    am = dg_amax_nan(dg_amax_nan(red[0], red[1]), dg_amax_nan(red[2], red[3]));
+    __syncthreads();
+    const float sc = dg_fp8_scale_of(am, 448.f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scale_inv[0] = 1.f / sc;
+    float qm = 0.f;
+    if (row0 < M) {
+#pragma unroll
+        for (int r = 0; r < LN_RPW; ++r) {
+            const int row = row0 + r;
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < LN_MAXV; ++k) s += (v[r][k][0] + v[r][k][1]) + (v[r][k][2] + v[r][k][3]);
+            const float mu = wave_sum(s) * invC;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < LN_MAXV; ++k) {
+                const int i = lane + k * 64;
+                if (i < nv) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float d = v[r][k][j] - mu; q += d * d; }
+                }
+            }
+            const float rs = rsqrtf(wave_sum(q) * invC + eps);
+            if (row < M) {
+                if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+                for (int k = 0; k < LN_MAXV; ++k) {
+                    const int i = lane + k * 64;
+                    if (i < nv) {
+                        float o[4], w4[4];
+                        bf16x4 ob;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            ob[j] = (bf16_t)((v[r][k][j] - mu) * rs * g[k][j] + b[k][j]);
+                            o[j] = (float)ob[j];                          // the cast sees the bf16 value, as the separate cast launch did
+                            qm = dg_amax_nan(qm, o[j]);
+                            w4[j] = dg_fp8_clamp(o[j] * sc, 448.f);
+                        }
+                        if (y) *(bf16x4*)(y + (int64_t)row * C + i * 4) = ob;
+                        int wq = 0;
+                        wq = __builtin_amdgcn_cvt_pk_fp8_f32(w4[0], w4[1], wq, false);
+                        wq = __builtin_amdgcn_cvt_pk_fp8_f32(w4[2], w4[3], wq, true);
+                        *(int*)(q8 + (int64_t)row * C + i * 4) = wq;
+                    }
+                }
+            }
+        }
+    }
+    qm = wave_amax_nan(qm);
+    if (lane == 0) red[w] = qm;
+    __syncthreads();
+    if (threadIdx.x == 0) next[blockIdx.x] = dg_amax_nan(dg_amax_nan(red[0], red[1]), dg_amax_nan(red[2], red[3]));
+}
+
+extern "C" int dg_layernorm_fwd_fp8_parts(int M) { return M > 0 ? (M + 4 * LN_RPW - 1) / (4 * LN_RPW) : 0; }
+
+extern "C" int dg_layernorm_fwd_fp8(const float* x, const float* gamma, const float* beta, void* y_bf16, void* q8, float* mean, float* rstd,
+                                    int M, int C, float eps, float* parts2, int n_parts, const uint32_t* step_state, float* scale_inv,
+                                    void* stream) {
+    if (!x || !gamma || !beta || !q8 || !mean || !rstd || !parts2 || !step_state || !scale_inv || M <= 0 || C <= 0) return DG_ERR_ARG;
+    if (C % 4 || C > 64 * 4 * 4 || n_parts != dg_layernorm_fwd_fp8_parts(M)) return DG_ERR_ARG;
+    if (!dg_aligned16(x) || !dg_aligned16(gamma) || !dg_aligned16(beta) || (y_bf16 && !dg_aligned16(y_bf16)) || (((uintptr_t)q8) & 3)) return DG_ERR_ALIGN;
+    const int nk = (C / 4 + 63) / 64;
+    dim3 grid(n_parts), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH8(K) hipLaunchKernelGGL((ln_fwd_fp8_kernel<K>), grid, block, 0, s, x, gamma, beta, (bf16_t*)y_bf16, (unsigned char*)q8, mean, rstd, M, C, eps, parts2, n_parts, step_state, scale_inv)
+    if (nk <= 1) LAUNCH8(1); else if (nk == 2) LAUNCH8(2); else if (nk == 3) LAUNCH8(3); else LAUNCH8(4);
+#undef LAUNCH8
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
 extern "C" int dg_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
                                 float* mean, float* rstd, int M, int C, float eps, void* stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || C <= 0) return DG_ERR_ARG;

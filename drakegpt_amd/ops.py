@@ -169,6 +169,36 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, out_dtype: torch.dtype
     return y, mean, rstd
 
 
+def layernorm_fwd_fp8_parts(M: int) -> int:
+    """partial maxima per history slot of layernorm_fwd_fp8 (one per workgroup of its launch)"""
+    return int(lib.dg_layernorm_fwd_fp8_parts(int(M)))
+
+
+def layernorm_fwd_fp8(x: Tensor, gamma: Tensor, beta: Tensor, parts2: Tensor, step_state: Tensor, want_bf16: bool = True, eps: float = 1e-5):
+    """LayerNorm whose output leaves as e4m3 with delayed scaling (parts2: fp32 [2 * layernorm_fwd_fp8_parts(M)], this call site's
+    history).  Returns (y bf16 -- unwritten and marked dg_unwritten when want_bf16 is False --, mean, rstd, q8, scale_inv [1])."""
+    _chk(x, "x", torch.float32)
+    _chk(gamma, "gamma", torch.float32)
+    _chk(beta, "beta", torch.float32)
+    _chk(parts2, "parts2", torch.float32)
+    _chk(step_state, "step_state", torch.int32)
+    Cd = x.shape[-1]
+    M = x.numel() // Cd
+    n = layernorm_fwd_fp8_parts(M)
+    if parts2.numel() != 2 * n:
+        raise RuntimeError(f"layernorm_fwd_fp8: parts2 must hold 2 x {n} floats")
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    q8 = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+    sinv = torch.empty((1,), dtype=torch.float32, device=x.device)
+    check(lib.dg_layernorm_fwd_fp8(_p(x), _p(gamma), _p(beta), _p(y) if want_bf16 else None, _p(q8), _p(mean), _p(rstd), M, Cd, eps, _p(parts2), n,
+                                   _p(step_state), _p(sinv), _stream()), "dg_layernorm_fwd_fp8")
+    if not want_bf16:
+        y.dg_unwritten = True
+    return y, mean, rstd, q8, sinv
+
+
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dresid: Optional[Tensor],
                   dgamma_part: Tensor, dbeta_part: Tensor, part_stride: int, n_partials: int,
                   dx: Optional[Tensor] = None) -> Tensor:

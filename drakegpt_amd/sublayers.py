@@ -251,6 +251,28 @@ def _op_dtype(run: Run, k: int, grad: bool = False):
     return None
 
 
+LN_FWD_FP8 = os.environ.get("DG_FP8_FUSED_LNF", "1") != "0"     # fp8 training: LayerNorm outputs leave their launch as e4m3 (A/B: 0 = cast launches)
+
+
+def _ln_fwd(run: Run, x2d: Tensor, ln_w: Tensor, ln_b: Tensor, site: str):
+    """LayerNorm forward -> (h, mean, rstd, x8).  Training engine in precision fp8 (history of call site `site` seeded): the output
+    leaves the LayerNorm launch as e4m3 with delayed scaling (x8 = (e4m3 copy, scale): what the cast launch in front of the next
+    GEMM would have produced one launch later), and where nobody reads the bf16 form (run.fp8_only) that form is not written."""
+    C = ln_w.numel()
+    ok = (run.fp8 and run.fp8_sites is not None and run.step_word is not None and run.act == torch.bfloat16 and LN_FWD_FP8
+          and C % 4 == 0 and C <= 1024 and fp8_k_ok(C) and x2d.dtype == torch.float32)
+    key = site + "#ln"
+    if ok and not run.fp8_seed and key in run.fp8_sites:
+        h, mean, rstd, q8, sinv = ops.layernorm_fwd_fp8(x2d, ln_w, ln_b, run.fp8_sites[key], run.step_word, want_bf16=not run.fp8_only)
+        return h, mean, rstd, (q8, sinv)
+    h, mean, rstd = ops.layernorm_fwd(x2d, ln_w, ln_b, run.act)
+    if ok and run.fp8_seed:
+        # (eager warm-up step) both history slots start at this batch's maximum
+        n = ops.layernorm_fwd_fp8_parts(x2d.shape[0])
+        run.fp8_sites[key] = h.detach().abs().max().float().reshape(1).expand(2 * n).contiguous()
+    return h, mean, rstd, None
+
+
 def _as_act(run: Run, x2d: Tensor) -> Tensor:
     return x2d if x2d.dtype == run.act else ops.cast(x2d, run.act)
 
@@ -304,13 +326,14 @@ def attn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tenso
     pre = (h, mean, rstd): the LayerNorm of x2d, already computed by the GEMM that produced x2d.  fuse_ln = (gamma, beta) of the
     LayerNorm that FOLLOWS this sub-layer: when the row-complete form is available the projection's epilogue also runs it and
     (h_next, mean, rstd) is appended to `nxt` (else nothing is appended and the caller runs the LayerNorm itself)."""
+    x8 = None
     if pre is not None:
         h, mean, rstd = pre
     elif ln_w is not None:
-        h, mean, rstd = ops.layernorm_fwd(x2d, ln_w, ln_b, run.act)
+        h, mean, rstd, x8 = _ln_fwd(run, x2d, ln_w, ln_b, f"{layer}.h1")
     else:
         h, mean, rstd = _as_act(run, x2d), None, None
-    qkv = linear_nt(run, h, wqkv, run.act, fp8_site=f"{layer}.h1")
+    qkv = linear_nt(run, h, wqkv, run.act, fp8_site=f"{layer}.h1", x8=x8)
     o, lse = ops.attn_fwd(qkv, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer), keep=True)     # (keep masks: only with dropout on)
     if wproj is not None:
         if fuse_ln is not None and nxt is not None and residual and o.shape[1] == x2d.shape[1] and _chain_ok(run, x2d, wproj):
@@ -366,15 +389,16 @@ def ffn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor
     """out_dtype: the engine asks for the activation type from the LAST block -- its output only feeds lm_head, which would
     cast it anyway (same rounding), so the fp32 copy and the cast launch disappear.  pre / fuse_ln / nxt: see attn_fwd (here
     the LayerNorm that follows is the NEXT block's first one, run by the second Linear's epilogue)."""
+    x8 = None
     if pre is not None:
         h, mean, rstd = pre
     elif ln_w is not None:
-        h, mean, rstd = ops.layernorm_fwd(x2d, ln_w, ln_b, run.act)
+        h, mean, rstd, x8 = _ln_fwd(run, x2d, ln_w, ln_b, f"{layer}.h2")
     else:
         h, mean, rstd = _as_act(run, x2d), None, None
     if w2 is None:
         # FeedForward: Linear(C,C) + ReLU (ref: src/model_component.py:118-121)
-        y = linear_nt(run, h, w1, torch.float32, bias=b1, relu=True)
+        y = linear_nt(run, h, w1, torch.float32, x8=x8, bias=b1, relu=True)
         return y, (x2d, h, mean, rstd, y, None)
     # the ReLU mask for backward travels as one bit per element next to f (1/16 of the bytes the dX GEMM would re-read)
     bits = None
@@ -382,7 +406,7 @@ def ffn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tensor
             and ops.gemm_nt_sign_bits_supported(run.act, w1.shape[0], w2.shape[0], in_dtype=_op_dtype(run, w2.shape[0], grad=True))):
         bits = ops.new_sign_bits(h.shape[0], w1.shape[0], h.device)
     f8 = _fused_fp8_out(run, f"{layer}.f", h.shape[0], w1.shape[0], w1.shape[1], h.device) if bits is not None else None
-    f = linear_nt(run, h, w1, run.act, fp8_site=f"{layer}.h2", bias=b1, relu=True, sign_bits_out=bits, fp8_out=f8,
+    f = linear_nt(run, h, w1, run.act, fp8_site=f"{layer}.h2", x8=x8, bias=b1, relu=True, sign_bits_out=bits, fp8_out=f8,
                   fp8_out_only=bool(f8 is not None and run.fp8_only and w2 is not None))
     if (fuse_ln is not None and nxt is not None and residual and out_dtype == torch.float32 and w1.shape[0] == 4 * x2d.shape[1]
             and _chain_ok(run, x2d, w2)):

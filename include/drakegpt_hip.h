@@ -90,6 +90,15 @@ int dg_embed_bwd(const int64_t* idx, const void* dx, int dx_dtype, float* dtok, 
  * y is written in y_dtype (the next GEMM's operand type). mean/rstd [M] are saved for bwd. */
 int dg_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
                      float* mean, float* rstd, int M, int C, float eps, void* stream);
+/* precision fp8 (round 3): the same LayerNorm with its output as OCP e4m3 (q8 [M][C] bytes: the operand of the fp8 GEMM that
+ * follows and of the fp8 dW launch) with delayed per-tensor scaling -- the value is first rounded to bf16, as the separate cast
+ * launch saw it -- one partial maximum per workgroup: parts2 [2][n_parts] floats with n_parts = dg_layernorm_fwd_fp8_parts(M)
+ * (slot step_state[2] & 1 written, the other read), *scale_inv the factor the consumer multiplies back.  y_bf16 nullable (nobody
+ * reads the bf16 form in the engine's fp8 step).  C % 4 == 0, C <= 1024. */
+int dg_layernorm_fwd_fp8_parts(int M);
+int dg_layernorm_fwd_fp8(const float* x, const float* gamma, const float* beta, void* y_bf16, void* q8, float* mean, float* rstd,
+                         int M, int C, float eps, float* parts2, int n_parts, const uint32_t* step_state, float* scale_inv,
+                         void* stream);
 /* dx = dresid (nullable, the residual branch's gradient) + LN'(dy).  dgamma/dbeta are emitted
  * as n_partials row-chunk partial sums: partial g at dgamma_part + g*part_stride (same for
  * dbeta_part); finish with dg_reduce_partials.  dy_dtype: DG_F32, or DG_BF16 (C % 4 == 0 only) when dy comes

@@ -476,7 +476,10 @@ def test_gpt2_medium_shape_fp8_engine_steps(dev):
         torch.cuda.synchronize()
         eng.check_status()
         if prec == "fp8":
-            assert len(eng.fp8_sites) == 8 * L + int(eng.fp8_head)     # every Linear of every block, forward and dX operands (+ the input of the fp8 lm_head)
+            # every Linear of every block, forward and dX operands (+ the input of the fp8 lm_head); round 3: + the two LayerNorm
+            # launches per block that emit their output as e4m3 themselves (their own history format: one partial per workgroup)
+            assert sum(1 for k in eng.fp8_sites if not k.endswith("#ln")) == 8 * L + int(eng.fp8_head)
+            assert sum(1 for k in eng.fp8_sites if k.endswith("#ln")) == 2 * L
         grads = {k: v.detach().clone() for k, v in eng.named_grads().items()}
         l1 = eng.step().item()                                 # same batch again, after one AdamW step: a graph replay
         assert math.isfinite(l0) and math.log(V) - 0.5 < l0 < math.log(V) + 3.0, l0
@@ -699,3 +702,36 @@ def test_fp8_only_outputs_equal_the_written_ones(dev):
     t.dg_unwritten = True
     with pytest.raises(RuntimeError):
         S._refuse_unwritten(t)
+
+
+@pytest.mark.parametrize("M,C", [(8192, 1024), (1000, 384), (64, 768)])
+def test_layernorm_fwd_fp8_equals_layernorm_plus_delayed_cast(dev, M, C):
+    """dg_layernorm_fwd_fp8 (round 3; ref: nn.LayerNorm at src/model_component.py:488-489, :505-506): the LayerNorm output as e4m3 with
+    delayed scaling from the LayerNorm launch itself, one partial maximum per workgroup -- against dg_layernorm_fwd followed by a cast
+    with the same scale (the previous slot's maximum): identical bytes, statistics and bf16 output, the recorded maximum = the
+    output's, the other slot untouched; with want_bf16=False the bf16 form is left alone and the tensor is marked."""
+    from drakegpt_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 1.7 + 0.3).to(dev)
+    gam, bet = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    n = ops.layernorm_fwd_fp8_parts(M)
+    state = ops.new_rng_state(5, dev, 6)                      # step word 6: slot 0 is written, slot 1 read
+    y0, mean0, rstd0 = ops.layernorm_fwd(x, gam, bet, torch.bfloat16)
+    prev_amax = 3.0
+    parts2 = torch.zeros(2 * n, device=dev)
+    parts2[n:] = torch.rand(n, generator=g).to(dev) * prev_amax
+    parts2[n + 7 % n] = prev_amax
+    before = parts2.clone()
+    y, mean, rstd, q8, sinv = ops.layernorm_fwd_fp8(x, gam, bet, parts2, state)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0) and torch.equal(mean, mean0) and torch.equal(rstd, rstd0)
+    sc = 448.0 / prev_amax
+    assert abs(sinv.item() - 1.0 / sc) < 1e-7
+    ref = (y0.float() * torch.tensor(sc, device=dev)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    assert torch.equal(q8.view(torch.uint8), ref.view(torch.uint8))
+    assert torch.equal(parts2[n:], before[n:])                                # the slot that was read
+    assert parts2[:n].max().item() == y0.float().abs().max().item()
+    y2, _, _, q8b, _ = ops.layernorm_fwd_fp8(x, gam, bet, before.clone(), state, want_bf16=False)
+    assert getattr(y2, "dg_unwritten", False) and torch.equal(q8b.view(torch.uint8), q8.view(torch.uint8))
+    with pytest.raises(RuntimeError):
+        ops.layernorm_fwd_fp8(x, gam, bet, parts2[:-1], state)
