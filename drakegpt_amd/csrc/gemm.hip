@@ -321,7 +321,10 @@ extern "C" int dg_gemm_nt(const dg_gemm_nt_args* a, void* stream) {
     { static const int rpf = [] { const char* e = getenv("DG_NT_RESPF"); return e ? atoi(e) : 0; }(); p.res_prefetch = rpf; }
     {   // weights of at most 2 MB (every block Linear of the scaled model; not lm_head at the GPT-2 vocabulary), one touch per lane
         static const int wm = [] { const char* e = getenv("DG_NT_WARM"); return e ? atoi(e) : 1; }();     // same box, headline step: 2.498 -> 2.478 ms
-        p.warm_b = (wm && (int64_t)a->N * a->ldb * esz <= (2 << 20) && (a->ldb * esz) % 128 == 0 && (((uintptr_t)a->B) & 127) == 0) ? 1 : 0;
+        // (wm = the largest operand in MB that is warmed: 2 by default; DG_NT_WARM=8 also covers the GPT-2 widths' matrices, which
+        // exceed an XCD's 4 MB of L2 -- A/B)
+        const int64_t wbytes = (int64_t)a->N * a->ldb * esz;
+        p.warm_b = (wm && wbytes <= ((int64_t)(wm < 2 ? 2 : wm) << 20) && (a->ldb * esz) % 128 == 0 && (((uintptr_t)a->B) & 127) == 0) ? (int)((wbytes + (2 << 20) - 1) >> 21) : 0;
     }
     p.stamps = g_stamp_buffer;
     const int tiles_m = (a->M + BM - 1) / BM;

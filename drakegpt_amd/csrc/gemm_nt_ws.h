@@ -597,9 +597,11 @@ __global__ __launch_bounds__(768) void gemm_nt_ws_kernel(NtParams p) {
     if (p.warm_b) {
         const int jx = (int)blockIdx.x >> 3, per = ((int)gridDim.x >> 3) ? ((int)gridDim.x >> 3) : 1;
         const int64_t n_lines = ((int64_t)p.N * p.ldb_b) >> 7;
-        const int64_t i = jx + (int64_t)per * tid;
         float wv = 0.f;
-        if (i < n_lines) asm volatile("global_load_dword %0, %1, off" : "=v"(wv) : "v"(p.B + i * 128) : "memory");
+        for (int rep = 0; rep < p.warm_b; ++rep) {                  // one touch per lane covers 2 MB (8 MFMA waves x 64 lanes x 32 workgroups x 128 B)
+            const int64_t i = jx + (int64_t)per * (tid + 512 * rep);
+            if (i < n_lines) asm volatile("global_load_dword %0, %1, off" : "=v"(wv) : "v"(p.B + i * 128) : "memory");
+        }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(wv) :: "memory");
     }
     u32x4 fa0[2], fb0[NJ], fa1[2], fb1[NJ];
