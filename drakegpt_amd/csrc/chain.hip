@@ -64,6 +64,7 @@ struct ChainP {
     float eps;
     const uint32_t* rng; uint32_t site_proj, site_ffn, thr; float inv_keep; int drop;
     int stagger;                         // experiment (DG_CHAIN_STAGGER): workgroup group g = (blockIdx / 8) % 4 starts g * stagger * 64 cycles late
+    unsigned long long* stamps;          // diagnostic (tools/chain_fwd_stamps.py): 24 s_memtime stamps per workgroup at the phase boundaries; NULL in production
     int dbg;                             // timing ablations (DG_CHAIN_DBG, results are wrong on purpose): 1 = every stage re-reads K step 0, 2 = no MFMA, 3 = no DMA after the prologue, 4 = no epilogues, 5 = 4 + idle loaders, 6 = no epilogue stores, 7 = no residual loads, 11 = no L2 warm-up of the weight stream
 };
 
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
         for (int q = 0; q < 3; ++q) {
             const int col = col_l + 32 * q;
             // (gamma / beta of block q + 1 requested ahead, like the residual operands: 2 us SLOWER per LayerNorm piece -- 32 more
-            // live registers and ten spills; the plain form it is)
+            // live registers and ten spills; requested for block 0 only, in front of the exchange barrier: ten spills again, for all
+            // three blocks there: sixty.  The plain form it is: three L2 round trips, ~4 000 of this epilogue's 19 500 cycles)
             const f32x4 g0 = *(const f32x4*)(gamma + col), g1 = *(const f32x4*)(gamma + col + 4);
             const f32x4 b0 = *(const f32x4*)(beta + col), b1 = *(const f32x4*)(beta + col + 4);
 #pragma unroll
@@ -392,6 +394,12 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
         // these waves would otherwise sit at the first barrier for as long
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) :: "memory");
     }
+    auto stamp = [&](int k) {
+        if (p.stamps && wave == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) p.stamps[(int64_t)blockIdx.x * 24 + k] = t;
+        }
+    };
     u32x4 fa0[2], fb0[6], fa1[2], fb1[6];
     for (int blk = blockIdx.x; blk < p.n_blocks; blk += gridDim.x) {
         const int64_t row0 = (int64_t)blk * CH_ROWS;
@@ -465,9 +473,11 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
             asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         };
+        stamp(0);
         if (HAS_PROJ) {
             // ---- proj + residual + LayerNorm 2
             piece(KS, false, HAS_FFN1, false, true);
+            stamp(1);
             if (p.dbg == 4 || p.dbg == 5) __builtin_amdgcn_s_barrier();
             else {
                 float xv[2][3][8];
@@ -475,10 +485,12 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
                 layernorm(xv, (float*)(lds + (g & (CH_NST - 1)) * CH_STAGE + CH_STAGE_B), row0, p.ln2w, p.ln2b, p.mean2, p.rstd2, p.h2);
             }
         }
+        stamp(2);
         if (HAS_FFN1) {
             // ---- FFN1: four column chunks of the hidden layer, bias + ReLU + sign bits
             for (int c = 0; c < 4; ++c) {
                 piece(KS, false, true, c == 0);
+                stamp(3 + 2 * c);
                 if (p.dbg == 4 || p.dbg == 5) continue;
                 const int lo = opaque_lane(), fr = lo & 15, fg = lo >> 4, col_l = wn * 96 + (fg & 1) * 16 + (fg >> 1) * 8;
                 const int lane = lo;
@@ -512,11 +524,13 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
                         }
                     }
                 }
+                stamp(4 + 2 * c);
             }
         }
         if (HAS_FFN2) {
             // ---- FFN2 + residual (+ LayerNorm 1 of the next block)
             piece(4 * KS, MODE != 4, HAS_QKV, false, true);
+            stamp(11);
             if (p.dbg == 4 || p.dbg == 5) { if (LN_FFN2) __builtin_amdgcn_s_barrier(); }
             else {
                 float xv[2][3][8];
@@ -525,10 +539,12 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
                     layernorm(xv, (float*)(lds + (g & (CH_NST - 1)) * CH_STAGE + CH_STAGE_B), row0, p.ln1w, p.ln1b, p.mean1, p.rstd1, p.h1);
             }
         }
+        stamp(12);
         if (HAS_QKV) {
             // ---- the next block's packed q / k / v: three column chunks, plain bf16 stores
             for (int c = 0; c < 3; ++c) {
                 piece(KS, false, c < 2, MODE == 0 && c == 0);
+                stamp(13 + 2 * c);
                 if (p.dbg == 4 || p.dbg == 5) continue;
                 const int lo = opaque_lane(), fr = lo & 15, fg = lo >> 4, col_l = wn * 96 + (fg & 1) * 16 + (fg >> 1) * 8;
 #pragma unroll
@@ -545,9 +561,12 @@ __global__ __launch_bounds__(768) void block_chain_fwd_kernel(ChainP p) {
                         if (p.dbg != 6) *(bf16x8*)(p.qkv + row * (3 * C) + col) = o;
                     }
                 }
+                stamp(14 + 2 * c);
             }
         }
+        stamp(19);
         __builtin_amdgcn_s_barrier();                                     // END
+        stamp(20);
     }
 }
 
@@ -628,6 +647,10 @@ static int ch_num_cus() {
 
 extern "C" int dg_block_chain_supported(int M, int C) { return M > 0 && M % CH_ROWS == 0 && C == CH_C; }
 
+static unsigned long long* g_chain_stamps = nullptr;
+// diagnostic only (tools/chain_fwd_stamps.py): not part of the public header
+extern "C" void dg_debug_set_chain_fwd_stamps(void* q) { g_chain_stamps = (unsigned long long*)q; }
+
 extern "C" int dg_block_chain_fwd(const dg_block_chain_args* a, void* stream) {
     if (!a || !dg_block_chain_supported(a->M, a->C)) return DG_ERR_ARG;
     if (a->mode < 0 || a->mode > 4) return DG_ERR_ARG;
@@ -656,6 +679,7 @@ extern "C" int dg_block_chain_fwd(const dg_block_chain_args* a, void* stream) {
     p.rng = a->rng_state; p.site_proj = a->site_proj; p.site_ffn = a->site_ffn;
     p.thr = dg_drop_threshold(a->dropout_p); p.inv_keep = 1.f / (1.f - a->dropout_p);
     { static const int dbg = [] { const char* e = getenv("DG_CHAIN_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
+    p.stamps = g_chain_stamps;
     { static const int st = [] { const char* e = getenv("DG_CHAIN_STAGGER"); return e ? atoi(e) : 0; }(); p.stagger = st; }
     const dim3 grid(p.n_blocks < ch_num_cus() ? p.n_blocks : ch_num_cus()), block(768);
     hipStream_t s = (hipStream_t)stream;
