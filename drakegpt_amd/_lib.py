@@ -18,7 +18,7 @@ DG_F32 = 0
 DG_BF16 = 1
 DG_FP8_E4M3 = 2
 DG_FP8_E5M2 = 3
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class GemmNtArgs(C.Structure):
@@ -131,6 +131,7 @@ SIGNATURES = {
     "dg_cast": [_vp, _i, _vp, _i, _i64, _vp],
     "dg_transpose_cast": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp],
     "dg_transpose_cast_batched": [_vp, _i, _i, _i, _i, _vp],
+    "dg_transpose_u8_batched": [_vp, _i, _i, _vp],
     "dg_attn_keep_bits_bytes": [_i, _i, _i, _i, _i],
     "dg_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp, _i64, _vp],
     "dg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp, _i64, _vp],

@@ -392,6 +392,77 @@ __global__ __launch_bounds__(256) void transpose_bf16_batched_kernel(const int64
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Byte transposition, batched (round 3, precision fp8): the e4m3 copy of every W^T from the e4m3 copy of W -- one byte per element
+// read and written (the bf16 transposition + a second cast moved five) -- in 128 x 128-byte tiles: rows into LDS, 4 x 4 byte blocks
+// transposed in registers into a second image, whole 128-byte rows out.  desc rows as for dg_transpose_cast_batched (tiles of 128).
+__global__ __launch_bounds__(256) void transpose_u8_batched_kernel(const int64_t* __restrict__ desc, int n_desc) {
+    constexpr int PITCH = 144;                                  // bytes: 16-byte aligned rows, rows 4 apart on different banks
+    __shared__ __attribute__((aligned(16))) unsigned char ta[128 * PITCH], tb[128 * PITCH];
+    int d = 0;
+    for (int i = 1; i < n_desc; ++i)
+        if ((int64_t)blockIdx.x >= desc[i * 8 + 6]) d = i;
+    const int64_t* D = desc + d * 8;
+    const unsigned char* in = (const unsigned char*)D[0];
+    unsigned char* out = (unsigned char*)D[1];
+    const int64_t ldi = D[2], ldo = D[3];
+    const int R = (int)D[4], Cc = (int)D[5];
+    const int local = (int)((int64_t)blockIdx.x - D[6]), tiles_x = (int)D[7];
+    const int r0 = (local / tiles_x) * 128, c0 = (local % tiles_x) * 128;
+    const bool vec = ((ldi | ldo) % 16 == 0) && ((((uintptr_t)in) | ((uintptr_t)out)) % 16 == 0);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int pc = threadIdx.x + 256 * pass, row = pc >> 3, ck = pc & 7;
+        const int r = r0 + row, c = c0 + 16 * ck;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r < R) {
+            const unsigned char* src = in + (int64_t)r * ldi + c;
+            if (vec && c + 16 <= Cc) v = *(const u32x4*)src;
+            else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (c + j < Cc) v[j >> 2] |= (uint32_t)src[j] << (8 * (j & 3));
+            }
+        }
+        *(u32x4*)(ta + row * PITCH + 16 * ck) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int blk = threadIdx.x + 256 * pass, br = blk >> 5, bc = blk & 31;         // 32 x 32 blocks of 4 x 4 bytes
+        uint32_t dd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dd[j] = *(const uint32_t*)(ta + (4 * br + j) * PITCH + 4 * bc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t t = ((dd[0] >> (8 * i)) & 0xFFu) | (((dd[1] >> (8 * i)) & 0xFFu) << 8) | (((dd[2] >> (8 * i)) & 0xFFu) << 16) | (((dd[3] >> (8 * i)) & 0xFFu) << 24);
+            *(uint32_t*)(tb + (4 * bc + i) * PITCH + 4 * br) = t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int pc = threadIdx.x + 256 * pass, row = pc >> 3, ck = pc & 7;          // out row = input column c0 + row
+        const int c = c0 + row, r = r0 + 16 * ck;
+        if (c >= Cc || r >= ldo) continue;
+        const u32x4 v = *(const u32x4*)(tb + row * PITCH + 16 * ck);
+        unsigned char* dst = out + (int64_t)c * ldo + r;
+        if (vec && r + 16 <= ldo) *(u32x4*)dst = v;
+        else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (r + j < ldo) dst[j] = (unsigned char)(v[j >> 2] >> (8 * (j & 3)));
+        }
+    }
+}
+
+extern "C" int dg_transpose_u8_batched(const int64_t* desc, int n_desc, int total_tiles, void* stream) {
+    if (!desc || n_desc <= 0 || total_tiles <= 0) return DG_ERR_ARG;
+    hipLaunchKernelGGL(transpose_u8_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc, n_desc);
+    DG_LAUNCH_CHECK();
+    return DG_OK;
+}
+
 extern "C" int dg_transpose_cast_batched(const int64_t* desc, int n_desc, int total_tiles, int in_dtype, int dtype, void* stream) {
     if (!desc || n_desc <= 0 || total_tiles <= 0) return DG_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;

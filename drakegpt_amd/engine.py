@@ -70,11 +70,14 @@ class ShadowWeights:
         self.bwd8_map: Dict[int, Tuple[Tensor, Tensor]] = {}
         self.pack_map: Dict[int, Tensor] = {}                      # proj / second FFN Linear in dg_block_chain_fwd's streaming order
         self.packT_map: Dict[int, Tensor] = {}                     # the W^T operands in dg_block_chain_bwd's streaming order
+        self.bwd_stale: set = set()                                # precision fp8: matrices whose bf16 W^T is no longer refreshed (only the e4m3 W^T is read)
 
     def fwd(self, W: Tensor) -> Tensor:
         return self.fwd_map[W.data_ptr()]
 
     def bwd(self, W: Tensor) -> Tensor:
+        if W.data_ptr() in self.bwd_stale:
+            raise RuntimeError("drakegpt_amd: the bf16 W^T of this matrix is not maintained in precision fp8 (its e4m3 W^T is)")
         return self.bwd_map[W.data_ptr()]
 
     def fwd8(self, W: Tensor):
@@ -468,6 +471,8 @@ class TrainEngine:
         self.wtpack_flat = torch.zeros(self.layA.size, dtype=torch.bfloat16, device=dev) if self.chain_bwd else None
         self._pack_pairs = []
         self._packT_pairs = []
+        self._u8_pairs = []
+        self.fp8_wt8 = self.fp8 and _os_env("DG_FP8_WT8", "1") != "0"
         for key, (off, shape) in self.layA.entries.items():
             W = self.param_view(key)
             n = shape[0] * shape[1]
@@ -492,7 +497,16 @@ class TrainEngine:
                 seg_f.append([off, n])
                 seg_b.append([wt_off, wt_sizes[key]])
                 self.weights.fwd8_map[W.data_ptr()] = (self.shadow8[off:off + n].view(shape), self.wscale_f[i:i + 1])
-                self.weights.bwd8_map[W.data_ptr()] = (self.wt8_flat[wt_off:wt_off + wt_sizes[key]].view(wt_shape), self.wscale_b[i:i + 1])
+                # round 3: the e4m3 W^T is the byte transposition of the e4m3 W (same values, same per-matrix scale) -- the bf16 W^T of
+                # these matrices is neither refreshed nor read (DG_FP8_WT8=0: bf16 transposition + a second cast, as before)
+                w8t = self.wt8_flat[wt_off:wt_off + wt_sizes[key]].view(wt_shape)
+                if self.fp8_wt8:
+                    self.weights.bwd8_map[W.data_ptr()] = (w8t, self.wscale_f[i:i + 1])
+                    if key != "lm.w":               # (lm_head keeps its bf16 W^T too: the keep_logits / fp32-logits paths take the bf16 dX GEMM)
+                        self.weights.bwd_stale.add(W.data_ptr())
+                    self._u8_pairs.append((self.shadow8[off:off + n].view(shape), w8t))
+                else:
+                    self.weights.bwd8_map[W.data_ptr()] = (w8t, self.wscale_b[i:i + 1])
             wt_off += _round(wt_sizes[key])
         if self.fp8:
             self.seg_f = torch.tensor(seg_f, dtype=torch.int64, device=dev)
@@ -510,9 +524,10 @@ class TrainEngine:
         # bf16: transpose the bf16 shadow the optimizer has just written (bit-identical to casting the fp32 master, half the read)
         from_shadow = self.shadow is not None
         if getattr(self, "_tr_table", None) is None:
-            pairs = [(self.weights.fwd(W) if from_shadow else W, Wt) for W, Wt in self._mats]
-            self._tr_table = ops.make_transpose_table(pairs, self.dev)
-        ops.transpose_cast_batched(*self._tr_table, self.act, in_dtype=torch.bfloat16 if from_shadow else torch.float32)
+            pairs = [(self.weights.fwd(W) if from_shadow else W, Wt) for W, Wt in self._mats if W.data_ptr() not in self.weights.bwd_stale]
+            self._tr_table = ops.make_transpose_table(pairs, self.dev) if pairs else ()
+        if self._tr_table:
+            ops.transpose_cast_batched(*self._tr_table, self.act, in_dtype=torch.bfloat16 if from_shadow else torch.float32)
         if self._pack_pairs:
             if getattr(self, "_pack_table", None) is None:
                 self._pack_table = ops.make_pack_table(self._pack_pairs + self._packT_pairs, self.dev)
@@ -522,8 +537,13 @@ class TrainEngine:
             n = self.seg_f.shape[0]
             ops.fp8_quantize(self.shadow[self.offA:self.offA + self.layA.size], S.E4M3, seg=self.seg_f, n_seg=n, out=self.shadow8,
                              scale_inv=self.wscale_f, amax=self.w_amax)
-            ops.fp8_quantize(self.wt_flat, S.E4M3, seg=self.seg_b, n_seg=n, out=self.wt8_flat, scale_inv=self.wscale_b, amax=self.w_amax,
-                             reuse_amax=True)          # W^T holds W's values: same per-matrix maxima, no second amax pass
+            if self.fp8_wt8:
+                if getattr(self, "_u8_table", None) is None:
+                    self._u8_table = ops.make_transpose_u8_table(self._u8_pairs, self.dev)
+                ops.transpose_u8_batched(*self._u8_table)
+            else:
+                ops.fp8_quantize(self.wt_flat, S.E4M3, seg=self.seg_b, n_seg=n, out=self.wt8_flat, scale_inv=self.wscale_b, amax=self.w_amax,
+                                 reuse_amax=True)          # W^T holds W's values: same per-matrix maxima, no second amax pass
 
     # -------------------------------------------------------------------------------- programs
     def _layer_params(self, l: int):

@@ -540,6 +540,23 @@ def make_transpose_table(pairs, device) -> tuple:
     return torch.tensor(rows, dtype=torch.int64, device=device), len(rows), first
 
 
+def make_transpose_u8_table(pairs, device) -> tuple:
+    """descriptor table for transpose_u8_batched: pairs = [(W8 [R, C] one-byte elements, Wt8 [C, ldo >= R])]"""
+    rows, first = [], 0
+    for W, Wt in pairs:
+        R, Cc = W.shape
+        ldo = Wt.shape[1]
+        tiles_x, tiles_y = (Cc + 127) // 128, (ldo + 127) // 128
+        rows.append([W.data_ptr(), Wt.data_ptr(), _ld(W), ldo, R, Cc, first, tiles_x])
+        first += tiles_x * tiles_y
+    return torch.tensor(rows, dtype=torch.int64, device=device), len(rows), first
+
+
+def transpose_u8_batched(table: Tensor, n_desc: int, total_tiles: int) -> None:
+    _chk(table, "table", torch.int64)
+    check(lib.dg_transpose_u8_batched(_p(table), n_desc, total_tiles, _stream()), "dg_transpose_u8_batched")
+
+
 def transpose_cast_batched(table: Tensor, n_desc: int, total_tiles: int, dtype: torch.dtype, in_dtype: torch.dtype = torch.float32) -> None:
     _chk(table, "table", torch.int64)
     check(lib.dg_transpose_cast_batched(_p(table), n_desc, total_tiles, dt_code(in_dtype), dt_code(dtype), _stream()), "dg_transpose_cast_batched")

@@ -493,16 +493,16 @@ def linear_bwd_from_act(run: Run, saved, g: Tensor, w: Tensor, has_bias: bool, s
     weight_grad(sink, keys["w"], g, xa, N, K)
     if not need_dx:
         return None
-    wt = run.weights.bwd(w)
-    Kp = k_pad(N, run.act)
-    if ops._ld(g) < Kp or wt.shape[1] < Kp:                       # caller padded to the granule only
-        Kp = pad_to(N, granule(run.act))
     d8 = getattr(g, "dg_fp8", None)
     w8 = getattr(run.weights, "bwd8_map", {}).get(w.data_ptr()) if run.fp8 else None
+    wt_cols = w8[0].shape[1] if w8 is not None else run.weights.bwd(w).shape[1]
+    Kp = k_pad(N, run.act)
+    if ops._ld(g) < Kp or wt_cols < Kp:                           # caller padded to the granule only
+        Kp = pad_to(N, granule(run.act))
     if d8 is not None and w8 is not None and fp8_k_ok(Kp) and ops._ld(d8[0]) >= Kp and w8[0].shape[1] >= Kp:
         # fp8 head: e5m2 dlogits (a-priori scale, from the loss kernel) x the e4m3 W^T shadow, contraction over the padded vocabulary
         return ops.gemm_nt(d8[0], w8[0], run.stream, K=Kp, scale_a=d8[1], scale_b=w8[1])
-    return ops.gemm_nt(g, wt, run.stream, K=Kp)                   # the head of the gradient stream
+    return ops.gemm_nt(g, run.weights.bwd(w), run.stream, K=Kp)   # the head of the gradient stream
 
 
 def linear_bwd(run: Run, saved, dy: Tensor, w: Tensor, has_bias: bool, sink, keys, need_dx: bool = True):

@@ -45,7 +45,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 18   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 19   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -293,6 +293,10 @@ int dg_transpose_cast(const float* in, int64_t ldi, void* out, int64_t ldo, int 
  * consecutive 64x64 tiles starting at first_tile (tiles_x = ceil(Cc/64)); total_tiles = their sum.
  * in_dtype: DG_F32 (the fp32 masters) or, for bf16 output, DG_BF16 (the bf16 shadow copy: same values, half the read). */
 int dg_transpose_cast_batched(const int64_t* desc, int n_desc, int total_tiles, int in_dtype, int out_dtype, void* stream);
+/* The same for one-byte elements (precision fp8: the e4m3 copy of every W^T from the e4m3 copy of W, scales unchanged), tiles of
+ * 128 x 128: first_tile / tiles_x of the desc rows count 128-wide tiles (tiles_x = ceil(Cc / 128), a matrix owns tiles_x *
+ * ceil(ldo / 128) of them).  Rows of `out` beyond R (ldo > R: padding) are written as zeros. */
+int dg_transpose_u8_batched(const int64_t* desc, int n_desc, int total_tiles, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Causal multi-head attention -- ref: Head2.forward src/model_component.py:392-405 for every

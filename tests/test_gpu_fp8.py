@@ -735,3 +735,20 @@ def test_layernorm_fwd_fp8_equals_layernorm_plus_delayed_cast(dev, M, C):
     assert getattr(y2, "dg_unwritten", False) and torch.equal(q8b.view(torch.uint8), q8.view(torch.uint8))
     with pytest.raises(RuntimeError):
         ops.layernorm_fwd_fp8(x, gam, bet, parts2[:-1], state)
+
+
+@pytest.mark.parametrize("R,Cc,ldo", [(1024, 4096, 1024), (384, 1152, 384), (80, 384, 128), (50257, 64, 50304), (130, 200, 144)])
+def test_transpose_u8_batched(dev, R, Cc, ldo):
+    """dg_transpose_u8_batched (round 3): the e4m3 W^T shadows as byte transpositions of the e4m3 W shadows -- exact, for whole and
+    ragged 128 x 128 tiles, a padded leading dimension (rows of the output beyond R written as zeros), several matrices per launch."""
+    from drakegpt_amd import ops
+    g = torch.Generator().manual_seed(R + Cc)
+    a = torch.randint(0, 256, (R, Cc), generator=g, dtype=torch.uint8).to(dev)
+    b = torch.randint(0, 256, (R // 2 + 1, 48), generator=g, dtype=torch.uint8).to(dev)
+    at = torch.full((Cc, ldo), 7, dtype=torch.uint8, device=dev)
+    bt = torch.full((48, R // 2 + 1), 7, dtype=torch.uint8, device=dev)
+    table = ops.make_transpose_u8_table([(a, at), (b, bt)], dev)
+    ops.transpose_u8_batched(*table)
+    torch.cuda.synchronize()
+    assert torch.equal(at[:, :R], a.t()) and torch.all(at[:, R:] == 0)
+    assert torch.equal(bt, b.t())
