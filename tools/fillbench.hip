@@ -241,7 +241,9 @@ __device__ __forceinline__ u32x4 tn_frag(const char* tile, int r0, int col0, int
     bf16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(u32x4, v);
 }
-template <int WM, int WN, int NW>      // NW MFMA waves; wave tile WM*16 x WN*16 of a 128 x 128 (NW=8, 2x4) or (NW=4, 4x4) tile
+// BPLAIN: the B operand's fragments as plain 16-byte reads out of a [128 q][64 r] image (rows of 128 B, chunk ^ (row & 7)): what the
+// dW kernel would do if a producer had left X^T behind (only dY through ds_read_b64_tr_b16)
+template <int WM, int WN, int NW, bool BPLAIN = false>      // NW MFMA waves; wave tile WM*16 x WN*16 of a 128 x 128 (NW=8, 2x4) or (NW=4, 4x4) tile
 __global__ __launch_bounds__(768) void tn_step_kernel(const char* src, size_t region, int iters, int with_dma, long long* out, float* sink) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -281,7 +283,13 @@ __global__ __launch_bounds__(768) void tn_step_kernel(const char* src, size_t re
 #pragma unroll
         for (int i = 0; i < WM; ++i) fa[i] = tn_frag(buf, r0, wp * WM * 16 + i * 16, lane);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) fb[j] = tn_frag(buf + 16384, r0, wq * WN * 16 + j * 16, lane);
+        for (int j = 0; j < WN; ++j) {
+            if (BPLAIN) {
+                const int row = wq * WN * 16 + j * 16 + (lane & 15), ch = ks * 4 + fg;
+                fb[j] = *(const u32x4*)(buf + 16384 + row * 128 + 16 * (ch ^ (row & 7)));
+            } else
+                fb[j] = tn_frag(buf + 16384, r0, wq * WN * 16 + j * 16, lane);
+        }
     };
     auto mm = [&](const u32x4 (&fa)[WM], const u32x4 (&fb)[WN]) {
 #pragma unroll
@@ -308,9 +316,9 @@ __global__ __launch_bounds__(768) void tn_step_kernel(const char* src, size_t re
     if (a == 123.456f) sink[0] = a;
     if (lane == 0 && wave == 0) out[blockIdx.x] = t1 - t0;
 }
-template <int WM, int WN, int NW>
+template <int WM, int WN, int NW, bool BPLAIN = false>
 static void run_tn(const char* name, const char* src, size_t region, int iters, long long* out, float* sink) {
-    CHECK(hipFuncSetAttribute((const void*)tn_step_kernel<WM, WN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CHECK(hipFuncSetAttribute((const void*)tn_step_kernel<WM, WN, NW, BPLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     std::vector<long long> h(256);
     for (int with_dma = 0; with_dma < 2; ++with_dma) {
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -318,7 +326,7 @@ static void run_tn(const char* name, const char* src, size_t region, int iters, 
         const int big = iters * 20;
         for (int rep = 0; rep < 2; ++rep) {
             CHECK(hipEventRecord(e0));
-            tn_step_kernel<WM, WN, NW><<<256, 64 * (NW + 4), 131072>>>(src, region, big, with_dma, out, sink);
+            tn_step_kernel<WM, WN, NW, BPLAIN><<<256, 64 * (NW + 4), 131072>>>(src, region, big, with_dma, out, sink);
             CHECK(hipEventRecord(e1));
             CHECK(hipDeviceSynchronize());
             CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -377,6 +385,7 @@ int main(int argc, char** argv) {
     run_tn<2, 4, 8>("8 waves of 32x64", src, region, iters, out, sink);
     run_tn<4, 4, 4>("4 waves of 64x64", src, region, iters, out, sink);
     run_tn<4, 4, 8>("8 waves of 64x64 (256x128 tile: halve the printed time per 128x128x64)", src, region, iters, out, sink);
+    run_tn<4, 4, 8, true>("8 waves of 64x64, B fragments by ds_read_b128 from an X^T image", src, region, iters, out, sink);
     run_step<2, 4>("8 waves of 32x64", 8, src, region, row_stride, iters, out, sink);
     if (argc > 1) return 0;
     for (int mode = 0; mode < 2; ++mode)
