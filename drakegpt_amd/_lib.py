@@ -18,7 +18,7 @@ DG_F32 = 0
 DG_BF16 = 1
 DG_FP8_E4M3 = 2
 DG_FP8_E5M2 = 3
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class GemmNtArgs(C.Structure):
@@ -86,6 +86,11 @@ class BlockChainBwdArgs(C.Structure):
     ]
 
 
+class AttnFp8Out(C.Structure):
+    """dg_attn_fp8_out (include/drakegpt_hip.h)"""
+    _fields_ = [("q8", C.c_void_p), ("hist3", C.c_void_p), ("step_state", C.c_void_p), ("scale_inv", C.c_void_p), ("only8", C.c_int)]
+
+
 class TnProblem(C.Structure):
     """struct dg_tn_problem"""
     _fields_ = [
@@ -135,6 +140,9 @@ SIGNATURES = {
     "dg_attn_keep_bits_bytes": [_i, _i, _i, _i, _i],
     "dg_attn_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp, _i64, _vp],
     "dg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp, _i64, _vp],
+    "dg_attn_fp8_out_supported": [_i, _i, _i, _i, _i],
+    "dg_attn_fwd_fp8": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp, _i64, C.POINTER(AttnFp8Out), _vp],
+    "dg_attn_bwd_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _vp, _u32, _i, _vp, _i64, C.POINTER(AttnFp8Out), _vp],
     "dg_attn_bwd_workspace_bytes": [_i, _i, _i, _i, _i],
     "dg_attn_decode": [_vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "dg_cross_entropy": [_vp, _i, _i64, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _i, _vp],

@@ -44,7 +44,64 @@ struct AttnP {
     unsigned long long* keep;
     unsigned long long* stamps;  // diagnostic (tools/attn_dq_stamps.py): per workgroup 8 words = cycles wave 0 spent in each phase of the dQ tile loop; NULL in production
     int tiles_mode;            // 1: 4 KB tiles [32 q][P | dS] (LDS-staged); 2: 2 KB tiles, the lanes' 16 signed probabilities as they hold them
+    // optional (round 3, precision fp8; the F8 template instances only): the output a second time as fp8 (o: e4m3, dqkv: e5m2; same
+    // [rows][columns] as the bf16 tensor, one byte per element) with delayed per-tensor scaling -- see attn_f8_begin
+    uint8_t* q8; float* hist3; const uint32_t* step; float* sinv; int only8;      // only8: the bf16 form is not written
 };
+// fp8 copy of an output from the kernel that produces it.  hist3 = [3][64] partial maxima owned by the call site, every one on a
+// 128-byte line of its own (DG_ATTN_F8_HIST floats in all): slot step % 3 collects THIS step's maxima (atomic max on the bit
+// patterns of non-negative floats -- NaN patterns compare above every finite one and poison the scale as everywhere else; wave w ->
+// partial w % 64), slot (step + 2) % 3 holds last step's (the scale this launch casts with: lane l reads partial l, one round trip),
+// slot (step + 1) % 3 is cleared here for the next step: nobody reads or accumulates into it during this step, so any wave of any
+// launch of the site may clear it.  Why a line per partial: atomics on one LINE serialise in the L2 at ~37 ns each and hold up the
+// channel's other traffic -- measured at the GPT-2-medium shape (4 096 waves per launch): 256 partials packed into 8 lines + 7..10 us
+// per dQ launch (111 -> 118..121 us), ONE word for the whole launch + 150 us (dQ 260 us, forward 212 us).  Several launches may
+// share one history (dQ and dK/dV: one tensor).  The caller seeds every partial with a just-in-time maximum before the first use.
+// Returns the scale (wave-uniform, in an SGPR).
+#define ATTN_F8_LINES 64
+#define ATTN_F8_STRIDE 32                       // floats per line
+__device__ __forceinline__ float attn_f8_begin(const AttnP& p, float fmax, int lane, int64_t gwave) {
+    const uint32_t st = p.step[2] % 3u;
+    const float* prev = p.hist3 + ((st + 2u) % 3u) * (ATTN_F8_LINES * ATTN_F8_STRIDE);
+    const float am = wave_amax_nan(prev[lane * ATTN_F8_STRIDE]);
+    const float sc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, dg_fp8_scale_of(am, fmax))));
+    if (gwave == 0 && lane == 0 && p.sinv) p.sinv[0] = 1.f / sc;
+    if (gwave < ATTN_F8_LINES && lane == 0) {
+        float* nxt = p.hist3 + ((st + 1u) % 3u) * (ATTN_F8_LINES * ATTN_F8_STRIDE);
+        for (int64_t i = gwave; i < ATTN_F8_LINES; i += p.n_items) nxt[i * ATTN_F8_STRIDE] = 0.f;
+    }
+    return sc;
+}
+__device__ __forceinline__ void attn_f8_end(const AttnP& p, float m, int lane, int64_t gwave) {
+    m = wave_amax_nan(m);
+    if (lane == 0) {
+        unsigned* cur = (unsigned*)(p.hist3 + (p.step[2] % 3u) * (ATTN_F8_LINES * ATTN_F8_STRIDE)) + (gwave % ATTN_F8_LINES) * ATTN_F8_STRIDE;
+        // the partial only grows during a step: a wave that does not raise it (nearly all of them, after the first few) leaves it at a load
+        const unsigned mb = __builtin_bit_cast(unsigned, m);
+        if (mb > __hip_atomic_load(cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            __hip_atomic_fetch_max(cur, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// one 16-byte chunk of a bf16 row image (8 values) -> 8 fp8 bytes at q; returns the running maximum of |values|
+template <bool BF8>
+__device__ __forceinline__ float attn_f8_chunk(u32x4 v, float sc, float m, uint8_t* q) {
+    const bf16x8 t = __builtin_bit_cast(bf16x8, v);
+    const float fmax = BF8 ? 57344.f : 448.f;
+    float w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float f = (float)t[e]; m = dg_amax_nan(m, f); w[e] = dg_fp8_clamp(f * sc, fmax); }
+    int lo = 0, hi = 0;
+    if (BF8) {
+        lo = __builtin_amdgcn_cvt_pk_bf8_f32(w[0], w[1], lo, false); lo = __builtin_amdgcn_cvt_pk_bf8_f32(w[2], w[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_bf8_f32(w[4], w[5], hi, false); hi = __builtin_amdgcn_cvt_pk_bf8_f32(w[6], w[7], hi, true);
+    } else {
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(w[0], w[1], lo, false); lo = __builtin_amdgcn_cvt_pk_fp8_f32(w[2], w[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(w[4], w[5], hi, false); hi = __builtin_amdgcn_cvt_pk_fp8_f32(w[6], w[7], hi, true);
+    }
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    *(i32x2*)q = (i32x2){lo, hi};
+    return m;
+}
 __device__ __forceinline__ int64_t attn_keep_index(const AttnP& p, int64_t bh, int qb, int kb) {       // in 128-byte records
     return bh * (p.nblk * (p.nblk + 1) / 2) + qb * (qb + 1) / 2 + kb;
 }
@@ -151,8 +208,12 @@ __device__ __forceinline__ void frags_global(bf16x8 (&f)[4], const bf16_t* base,
 }
 // store a transposed accumulator pair (acc[dt][reg]: row d = 32*dt + krow(reg,hh), col = query lane&31)
 // as rows [32 queries][64 d] bf16 through the wave's LDS slice
+// F8: 0 none; 1 / 2: every chunk also as e4m3 / e5m2 at base8 (same element offsets, scale sc; *amax = running maximum of the
+// bf16-rounded values, what a cast launch behind this store would have seen); only8: the bf16 chunk is not stored
+template <int F8 = 0>
 __device__ __forceinline__ void store_T_acc(char* img, const f32x16 (&acc)[2], float mul_lane, bf16_t* base, int64_t ld,
-                                            int row0, int T, int lane) {
+                                            int row0, int T, int lane, uint8_t* base8 = nullptr, float sc = 0.f, float* amax = nullptr,
+                                            bool only8 = false) {
     const int c = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -170,12 +231,17 @@ __device__ __forceinline__ void store_T_acc(char* img, const f32x16 (&acc)[2], f
         const int cc = lane + 64 * i, row = cc >> 3, ch = cc & 7;
         const int gr = row0 + row;
         u32x4 v = *(const u32x4*)(img + row * 128 + ((ch ^ (row & 7)) << 4));
-        if (gr < T) *(u32x4*)(base + (int64_t)gr * ld + ch * 8) = v;
+        if (gr < T) {
+            if (!F8 || !only8) *(u32x4*)(base + (int64_t)gr * ld + ch * 8) = v;
+            if (F8) *amax = attn_f8_chunk<F8 == 2>(v, sc, *amax, base8 + (int64_t)gr * ld + ch * 8);
+        }
     }
 }
 // store an accumulator pair with rows on regs and d on lanes (acc[dt][reg]: row = krow(reg,hh), col d = 32*dt + lane&31)
+template <int F8 = 0>
 __device__ __forceinline__ void store_N_acc(char* img, const f32x16 (&acc)[2], float mul, bf16_t* base, int64_t ld,
-                                            int row0, int T, int lane) {
+                                            int row0, int T, int lane, uint8_t* base8 = nullptr, float sc = 0.f, float* amax = nullptr,
+                                            bool only8 = false) {
     const int c = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -187,13 +253,17 @@ __device__ __forceinline__ void store_N_acc(char* img, const f32x16 (&acc)[2], f
         const int cc = lane + 64 * i, row = cc >> 3, ch = cc & 7;
         const int gr = row0 + row;
         u32x4 v = *(const u32x4*)(img + row * 128 + ch * 16);
-        if (gr < T) *(u32x4*)(base + (int64_t)gr * ld + ch * 8) = v;
+        if (gr < T) {
+            if (!F8 || !only8) *(u32x4*)(base + (int64_t)gr * ld + ch * 8) = v;
+            if (F8) *amax = attn_f8_chunk<F8 == 2>(v, sc, *amax, base8 + (int64_t)gr * ld + ch * 8);
+        }
     }
 }
 
 #define WAVE_LDS_FWD 8192
 // =============================================================================================
-template <bool DROP, bool KEEP = false>      // dropout on the probabilities (compile-time: no per-element uniform branch); KEEP: also leave the keep masks (AttnP::keep)
+// F8: the output also as e4m3 (AttnP::q8 ...; precision fp8: the operand of the projection and of its weight gradient)
+template <bool DROP, bool KEEP = false, bool F8 = false>      // dropout on the probabilities (compile-time: no per-element uniform branch); KEEP: also leave the keep masks (AttnP::keep)
 __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block, pointers and loop bounds live in SGPRs
@@ -316,7 +386,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
     tile(std::true_type{}, qb);
     lsum += __shfl_xor(lsum, 32, 64);
     if (hh == 0 && qi < T) p.lse[bh * T + qi] = (m + log2f(lsum)) * (1.f / LOG2E);
-    store_T_acc(imgK, O, 1.f / lsum, p.out_w + (int64_t)b * T * C + h * HD, C, q0, T, lane);
+    if (F8) {
+        // (the scale is fetched here, behind the tile loop: nothing of it lives across the loop, and the other waves of the SIMD cover the round trip)
+        const float f8sc = attn_f8_begin(p, 448.f, lane, bh * p.nblk + blk);
+        float am = 0.f;
+        store_T_acc<1>(imgK, O, 1.f / lsum, p.out_w + (int64_t)b * T * C + h * HD, C, q0, T, lane, p.q8 + (int64_t)b * T * C + h * HD, f8sc, &am,
+                       p.only8 != 0);
+        attn_f8_end(p, am, lane, bh * p.nblk + blk);
+    } else
+        store_T_acc(imgK, O, 1.f / lsum, p.out_w + (int64_t)b * T * C + h * HD, C, q0, T, lane);
 }
 
 // =============================================================================================
@@ -493,7 +571,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma2_kernel(AttnP p) {
 // dropout-0 step slower than a dropout-0.2 step.  The no-dropout variant therefore takes two workgroups per CU and no spills.
 // TM: what the pass leaves behind for the dK/dV pass -- 0 nothing, 1 the [32 q][P | dS] tiles, 2 the signed probabilities only
 // KB: the keep decisions come as wave masks from the forward pass (AttnP::keep) instead of being hashed again
-template <bool DROP, int TM, bool KB = false>      // dropout on the probabilities (compile-time: no per-element uniform branch)
+// F8: dQ also as e5m2 into the fp8 copy of dqkv (AttnP::q8 ...; the dK/dV pass adds its two thirds under the same history)
+template <bool DROP, int TM, bool KB = false, bool F8 = false>      // dropout on the probabilities (compile-time: no per-element uniform branch)
 __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block, pointers and loop bounds live in SGPRs
@@ -680,7 +759,14 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
         for (int k = 0; k < 5; ++k) p.stamps[(int64_t)blockIdx.x * 8 + k] = st_acc[k];
         p.stamps[(int64_t)blockIdx.x * 8 + 5] = (unsigned long long)(qb + 1);
     }
-    store_T_acc(imgK, dQ, p.scale, p.dqkv + (int64_t)b * T * ld + h * HD, ld, q0, T, lane);
+    if (F8) {
+        const float f8sc = attn_f8_begin(p, 57344.f, lane, bh * p.nblk + blk);
+        float am = 0.f;
+        store_T_acc<2>(imgK, dQ, p.scale, p.dqkv + (int64_t)b * T * ld + h * HD, ld, q0, T, lane, p.q8 + (int64_t)b * T * ld + h * HD, f8sc, &am,
+                       p.only8 != 0);
+        attn_f8_end(p, am, lane, bh * p.nblk + blk);
+    } else
+        store_T_acc(imgK, dQ, p.scale, p.dqkv + (int64_t)b * T * ld + h * HD, ld, q0, T, lane);
 }
 
 // =============================================================================================
@@ -810,7 +896,8 @@ bool dg_attn_mfma_supported(int B, int T, int NH, int H) {
 // no dropout hash, no K / V operands: 8 MFMAs per tile, three 4 KB tiles staged per iteration (P|dS, Q, dO), all read
 // with transposed LDS reads.  ~140 VGPRs, 12 KB of LDS per wave: three workgroups per CU, every wave resident at once.
 #define WAVE_LDS_DKVT 12288
-__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_tiles_kernel(AttnP p) {
+template <bool F8>         // F8: dK and dV also as e5m2 into the fp8 copy of dqkv (the history the dQ pass of the same step used)
+__device__ __forceinline__ void attn_bwd_dkv_tiles_body(const AttnP& p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block, pointers and loop bounds live in SGPRs
     int64_t bh; int blk; bool valid;
@@ -860,10 +947,22 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_tiles_kernel(AttnP p) {
         __builtin_amdgcn_wave_barrier();
     }
     bf16_t* dKb = p.dqkv + (int64_t)b * T * ld + C + h * HD;
+    if (F8) {
+        uint8_t* dK8 = p.q8 + (int64_t)b * T * ld + C + h * HD;
+        const float f8sc = attn_f8_begin(p, 57344.f, lane, bh * p.nblk + blk);
+        float am = 0.f;
+        store_N_acc<2>(imgP, dK, p.scale, dKb, ld, k0, T, lane, dK8, f8sc, &am, p.only8 != 0);
+        __builtin_amdgcn_wave_barrier();
+        store_N_acc<2>(imgP, dV, 1.f, dKb + C, ld, k0, T, lane, dK8 + C, f8sc, &am, p.only8 != 0);
+        attn_f8_end(p, am, lane, bh * p.nblk + blk);
+        return;
+    }
     store_N_acc(imgP, dK, p.scale, dKb, ld, k0, T, lane);
     __builtin_amdgcn_wave_barrier();
     store_N_acc(imgP, dV, 1.f, dKb + C, ld, k0, T, lane);
 }
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_tiles_kernel(AttnP p) { attn_bwd_dkv_tiles_body<false>(p); }
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_tiles_f8_kernel(AttnP p) { attn_bwd_dkv_tiles_body<true>(p); }
 
 // =============================================================================================
 // dK/dV from the SIGNED-PROBABILITY tiles of the dQ pass (tiles_mode 2): per 32 x 32 tile the dQ pass leaves 2 KB -- every lane's 16
@@ -1010,15 +1109,41 @@ int64_t dg_attn_mfma_keep_bytes(int B, int T, int NH) {
     return (int64_t)B * NH * (nblk * (nblk + 1) / 2) * 128;
 }
 
+static int attn_tile_mode() {
+    static const int tile_mode = [] { const char* e = getenv("DG_ATTN_TILES"); return e ? atoi(e) : 1; }();   // 1 = P | dS tiles (default), 2 = signed P tiles (measured slower), 0 = recompute in the dK/dV pass
+    return tile_mode;
+}
+static int attn_shared_mode() {
+    static const int shared_mode = [] { const char* e = getenv("DG_ATTN_SHARED"); return e ? atoi(e) : 0; }();   // 1 = shared 64-key tiles (measured slower, see attn_fwd_mfma2_kernel)
+    return shared_mode;
+}
+// can the kernels leave their outputs as fp8 too (DgAttnF8)?  The default kernel forms only.
+bool dg_attn_mfma_f8_supported() { return attn_tile_mode() == 1 && !attn_shared_mode(); }
+
+static int attn_f8_fill(AttnP& p, const dg_attn_fp8_out* f8) {
+    if (!f8->q8 || !f8->hist3 || !f8->step_state || !f8->scale_inv || !dg_aligned16(f8->q8) || !dg_aligned16(f8->hist3)) return DG_ERR_ARG;
+    p.q8 = (uint8_t*)f8->q8; p.hist3 = f8->hist3; p.step = f8->step_state; p.sinv = f8->scale_inv; p.only8 = f8->only8;
+    return DG_OK;
+}
+
 int dg_attn_fwd_mfma(const void* qkv, void* out, float* lse, int B, int T, int NH, int H, float scale, float dp,
-                     const uint32_t* rng, uint32_t site, void* keep, hipStream_t s) {
+                     const uint32_t* rng, uint32_t site, void* keep, const dg_attn_fp8_out* f8, hipStream_t s) {
     if (dp < 0.f || dp >= 1.f || !dg_aligned16(qkv) || !dg_aligned16(out) || (keep && !dg_aligned16(keep))) return DG_ERR_ARG;
     AttnP p = {};
     fill(p, B, T, NH, scale, dp, rng, site);
     p.qkv = (const bf16_t*)qkv; p.out_w = (bf16_t*)out; p.lse = lse;
     p.keep = (unsigned long long*)keep;
     dim3 grid((unsigned)((p.n_items + 3) / 4)), block(256);
-    static const int shared_mode = [] { const char* e = getenv("DG_ATTN_SHARED"); return e ? atoi(e) : 0; }();   // 1 = shared 64-key tiles (measured slower, see attn_fwd_mfma2_kernel)
+    const int shared_mode = attn_shared_mode();
+    if (f8) {
+        if (!dg_attn_mfma_f8_supported() || (p.drop && !p.keep)) return DG_ERR_ARG;
+        if (int rc = attn_f8_fill(p, f8)) return rc;
+        if (p.only8) return DG_ERR_ARG;                   // (the dQ pass reads the bf16 output: delta = rowsum(dO o))
+        if (p.drop) hipLaunchKernelGGL((attn_fwd_mfma_kernel<true, true, true>), grid, block, 4 * WAVE_LDS_FWD, s, p);
+        else hipLaunchKernelGGL((attn_fwd_mfma_kernel<false, false, true>), grid, block, 4 * WAVE_LDS_FWD, s, p);
+        DG_LAUNCH_CHECK();
+        return DG_OK;
+    }
     if (shared_mode && p.balance && T % 64 == 0 && !keep) {      // balance: nblk % 4 == 0, i.e. T % 128 == 0 (whole 64-key tiles)
         if (p.drop) hipLaunchKernelGGL(attn_fwd_mfma2_kernel<true>, grid, block, 2 * FWD2_BUF, s, p);
         else hipLaunchKernelGGL(attn_fwd_mfma2_kernel<false>, grid, block, 2 * FWD2_BUF, s, p);
@@ -1039,7 +1164,8 @@ int64_t dg_attn_bwd_mfma_tile_bytes(int B, int T, int NH) {
 }
 
 int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, void* tiles,
-                     int B, int T, int NH, int H, float scale, float dp, const uint32_t* rng, uint32_t site, const void* keep, hipStream_t s) {
+                     int B, int T, int NH, int H, float scale, float dp, const uint32_t* rng, uint32_t site, const void* keep,
+                     const dg_attn_fp8_out* f8, hipStream_t s) {
     if (dp < 0.f || dp >= 1.f || !dg_aligned16(qkv) || !dg_aligned16(out) || !dg_aligned16(dout) || !dg_aligned16(dqkv)) return DG_ERR_ARG;
     if (keep && !dg_aligned16(keep)) return DG_ERR_ALIGN;
     if (tiles && !dg_aligned16(tiles)) return DG_ERR_ALIGN;
@@ -1047,7 +1173,7 @@ int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const f
     fill(p, B, T, NH, scale, dp, rng, site);
     p.qkv = (const bf16_t*)qkv; p.out = (const bf16_t*)out; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv;
     p.lse_r = lse; p.delta = delta; p.delta_r = delta;
-    static const int tile_mode = [] { const char* e = getenv("DG_ATTN_TILES"); return e ? atoi(e) : 1; }();   // 1 = P | dS tiles (default), 2 = signed P tiles (measured slower), 0 = recompute in the dK/dV pass
+    const int tile_mode = attn_tile_mode();
     p.tiles = tile_mode ? (char*)tiles : nullptr;
     p.tiles_mode = tile_mode == 1 ? 1 : 2;
     // keep masks from the forward pass: the default tile form (DG_ATTN_TILES=1) only; DG_ATTN_KEEPBITS=0 ignores them (A/B runs)
@@ -1060,6 +1186,22 @@ int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const f
     // read from any readable device words (the head of qkv): with threshold 0 its value cannot matter.  DG_ATTN_DQ_NODROP=1 restores it.
     static const int nodrop_variant = [] { const char* e = getenv("DG_ATTN_DQ_NODROP"); return e ? atoi(e) : 0; }();
     const int tm = p.tiles ? p.tiles_mode : 0;
+    if (f8) {
+        // dqkv also as e5m2: dQ from the dQ pass, dK / dV from the tile pass, one history, one scale
+        if (!dg_attn_mfma_f8_supported() || tm != 1) return DG_ERR_ARG;
+        if (int rc = attn_f8_fill(p, f8)) return rc;
+        if (p.drop && p.keep) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, true, true>), grid, block, 4 * WAVE_LDS_DQ, s, p);
+        else {
+            AttnP q = p;
+            if (!p.drop) { q.thr = 0u; q.inv_keep = 1.f; q.rng = (const uint32_t*)qkv; q.site = 0; }     // (as below: the DROP code with a threshold of 0)
+            hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, false, true>), grid, block, 4 * WAVE_LDS_DQ, s, q);
+        }
+        DG_LAUNCH_CHECK();
+        p.sinv = nullptr;                                 // (written by the dQ pass)
+        hipLaunchKernelGGL(attn_bwd_dkv_tiles_f8_kernel, grid, block, 4 * WAVE_LDS_DKVT, s, p);
+        DG_LAUNCH_CHECK();
+        return DG_OK;
+    }
 #define DQ_LAUNCH(DROP_, Q_) do { \
         if (tm == 2) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DROP_, 2>), grid, block, 4 * WAVE_LDS_DQ, s, Q_); \
         else if (tm == 1) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DROP_, 1>), grid, block, 4 * WAVE_LDS_DQ, s, Q_); \

@@ -20,6 +20,7 @@ Tensor = torch.Tensor
 _DT = {torch.float32: DG_F32, torch.bfloat16: DG_BF16, torch.float8_e4m3fn: DG_FP8_E4M3, torch.float8_e5m2: DG_FP8_E5M2}
 FP8_DTYPES = (torch.float8_e4m3fn, torch.float8_e5m2)
 FP8_AMAX_PARTS = 256            # DG_FP8_AMAX_PARTS
+ATTN_FP8_HIST = 3 * 64 * 32     # DG_ATTN_FP8_HIST
 
 
 def dt_code(dtype: torch.dtype) -> int:
@@ -562,9 +563,34 @@ def transpose_cast_batched(table: Tensor, n_desc: int, total_tiles: int, dtype: 
     check(lib.dg_transpose_cast_batched(_p(table), n_desc, total_tiles, dt_code(in_dtype), dt_code(dtype), _stream()), "dg_transpose_cast_batched")
 
 
+def attn_fp8_out_supported(B: int, T: int, NH: int, H: int, dtype: torch.dtype) -> bool:
+    """can attn_fwd / attn_bwd leave their outputs as fp8 too (fp8_out=...)?"""
+    return bool(lib.dg_attn_fp8_out_supported(B, T, NH, H, dt_code(dtype)))
+
+
+def new_attn_fp8_history(amax: Tensor) -> Tensor:
+    """history of an attention fp8 call site (DG_ATTN_FP8_HIST floats: three slots of 64 partial maxima, one 128-byte line each --
+    view(3, 64, 32)[s, i, 0]), every word seeded with `amax` (a device scalar)"""
+    return amax.detach().float().reshape(1).expand(ATTN_FP8_HIST).contiguous()
+
+
+def _attn_fp8_arg(fp8_out, shape, fmt: torch.dtype, dev, only8: bool = False):
+    """fp8_out = (hist3, step_state) -> (struct, q8, scale_inv)"""
+    from ._lib import AttnFp8Out
+    hist3, step_state = fp8_out
+    _chk(hist3, "hist3", torch.float32)
+    if hist3.numel() != ATTN_FP8_HIST:
+        raise RuntimeError("attention fp8 history must hold ATTN_FP8_HIST floats (ops.new_attn_fp8_history)")
+    q8 = torch.empty(shape, dtype=fmt, device=dev)
+    sinv = torch.empty((1,), dtype=torch.float32, device=dev)
+    return AttnFp8Out(_p(q8), _p(hist3), _p(step_state), _p(sinv), 1 if only8 else 0), q8, sinv
+
+
 def attn_fwd(qkv: Tensor, B: int, T: int, NH: int, H: int, scale: float, p: float, rng_state: Optional[Tensor], site: int,
-             keep: bool = False):
-    """keep=True (training with dropout, a backward pass follows): the forward pass also leaves its dropout keep decisions as
+             keep: bool = False, fp8_out=None):
+    """fp8_out = (hist3, step_state) (precision fp8, attn_fp8_out_supported): the output also as e4m3 with delayed scaling -- the
+    attribute `dg_fp8` = (e4m3 copy, scale_inv) travels with it.
+    keep=True (training with dropout, a backward pass follows): the forward pass also leaves its dropout keep decisions as
     wave masks (dg_attn_keep_bits_bytes; 128 bytes per unmasked 32 x 32 tile) -- they travel with the output as its attribute
     `dg_keep` and attn_bwd(..., keep_bits=out.dg_keep) selects with them instead of hashing again.  Shapes on the generic
     kernels have no such path (no attribute is set)."""
@@ -578,16 +604,26 @@ def attn_fwd(qkv: Tensor, B: int, T: int, NH: int, H: int, scale: float, p: floa
         n = int(lib.dg_attn_keep_bits_bytes(B, T, NH, H, dt_code(qkv.dtype)))
         if n > 0:
             kb = torch.empty(n, dtype=torch.uint8, device=qkv.device)
-    check(lib.dg_attn_fwd(_p(qkv), _p(out), _p(lse), B, T, NH, H, float(scale), float(p), _p(rng_state) if p > 0.0 else None,
-                          site, dt_code(qkv.dtype), _p(kb), kb.numel() if kb is not None else 0, _stream()), "dg_attn_fwd")
+    if fp8_out is not None:
+        import ctypes
+        arg, q8, sinv = _attn_fp8_arg(fp8_out, (B * T, NH * H), torch.float8_e4m3fn, qkv.device)
+        check(lib.dg_attn_fwd_fp8(_p(qkv), _p(out), _p(lse), B, T, NH, H, float(scale), float(p), _p(rng_state) if p > 0.0 else None,
+                                  site, dt_code(qkv.dtype), _p(kb), kb.numel() if kb is not None else 0, ctypes.byref(arg), _stream()),
+              "dg_attn_fwd_fp8")
+        out.dg_fp8 = (q8, sinv)
+    else:
+        check(lib.dg_attn_fwd(_p(qkv), _p(out), _p(lse), B, T, NH, H, float(scale), float(p), _p(rng_state) if p > 0.0 else None,
+                              site, dt_code(qkv.dtype), _p(kb), kb.numel() if kb is not None else 0, _stream()), "dg_attn_fwd")
     if kb is not None:
         out.dg_keep = kb
     return out, lse
 
 
 def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, T: int, NH: int, H: int, scale: float, p: float,
-             rng_state: Optional[Tensor], site: int, keep_bits: Optional[Tensor] = None) -> Tensor:
-    """keep_bits: the forward pass's keep masks (attn_fwd(..., keep=True) leaves them as out.dg_keep); default: taken from `out`"""
+             rng_state: Optional[Tensor], site: int, keep_bits: Optional[Tensor] = None, fp8_out=None, fp8_out_only: bool = False) -> Tensor:
+    """keep_bits: the forward pass's keep masks (attn_fwd(..., keep=True) leaves them as out.dg_keep); default: taken from `out`.
+    fp8_out = (hist3, step_state): dqkv also as e5m2 (attribute `dg_fp8` = (e5m2 copy, scale_inv)); fp8_out_only: the bf16 dqkv is
+    not written (marked `dg_unwritten`)."""
     _chk(qkv, "qkv")
     if keep_bits is None:
         keep_bits = getattr(out, "dg_keep", None)
@@ -598,6 +634,16 @@ def attn_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, B: int, T: int
     _chk(lse, "lse", torch.float32)
     dqkv = torch.empty_like(qkv)
     ws = torch.empty(int(lib.dg_attn_bwd_workspace_bytes(B, T, NH, H, dt_code(qkv.dtype))), dtype=torch.uint8, device=qkv.device)
+    if fp8_out is not None:
+        import ctypes
+        arg, q8, sinv = _attn_fp8_arg(fp8_out, tuple(qkv.shape), torch.float8_e5m2, qkv.device, only8=fp8_out_only)
+        check(lib.dg_attn_bwd_fp8(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(ws), ws.numel(), B, T, NH, H, float(scale), float(p),
+                                  _p(rng_state) if p > 0.0 else None, site, dt_code(qkv.dtype), _p(keep_bits),
+                                  keep_bits.numel() if keep_bits is not None else 0, ctypes.byref(arg), _stream()), "dg_attn_bwd_fp8")
+        dqkv.dg_fp8 = (q8, sinv)
+        if fp8_out_only:
+            dqkv.dg_unwritten = True
+        return dqkv
     check(lib.dg_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(ws), ws.numel(), B, T, NH, H, float(scale), float(p),
                           _p(rng_state) if p > 0.0 else None, site, dt_code(qkv.dtype), _p(keep_bits),
                           keep_bits.numel() if keep_bits is not None else 0, _stream()), "dg_attn_bwd")

@@ -273,6 +273,24 @@ def _ln_fwd(run: Run, x2d: Tensor, ln_w: Tensor, ln_b: Tensor, site: str):
     return h, mean, rstd, None
 
 
+ATTN_FP8_OUT = os.environ.get("DG_FP8_FUSED_ATTN", "1") != "0"     # fp8 training: o / dqkv leave the attention kernels as e4m3 / e5m2 too (A/B: 0 = cast launches)
+
+
+def _attn_fp8_out(run: Run, key: str, t: Optional[Tensor], B: int, T: int, NH: int, H: int, k: int):
+    """fp8_out argument of ops.attn_fwd / ops.attn_bwd for call site `key` (training engine, precision fp8, the consumer's
+    contraction length k takes the fp8 GEMM): (history, step words) once the history is seeded, else None.  During the engine's
+    eager warm-up step (`t` = the tensor the unfused path just produced) the history is seeded with that tensor's maximum."""
+    if not (ATTN_FP8_OUT and run.fp8 and run.fp8_sites is not None and run.step_word is not None and run.act == torch.bfloat16
+            and fp8_k_ok(k) and ops.attn_fp8_out_supported(B, T, NH, H, run.act)):
+        return None
+    if run.fp8_seed:
+        if t is not None:
+            run.fp8_sites[key] = ops.new_attn_fp8_history(t.detach().abs().max())
+        return None
+    hist = run.fp8_sites.get(key)
+    return None if hist is None else (hist, run.step_word)
+
+
 def _as_act(run: Run, x2d: Tensor) -> Tensor:
     return x2d if x2d.dtype == run.act else ops.cast(x2d, run.act)
 
@@ -334,7 +352,12 @@ def attn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tenso
     else:
         h, mean, rstd = _as_act(run, x2d), None, None
     qkv = linear_nt(run, h, wqkv, run.act, fp8_site=f"{layer}.h1", x8=x8)
-    o, lse = ops.attn_fwd(qkv, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer), keep=True)     # (keep masks: only with dropout on)
+    okey = f"{layer}.o#attn"
+    f8 = _attn_fp8_out(run, okey, None, B, T, NH, H, NH * H) if wproj is not None else None
+    o, lse = ops.attn_fwd(qkv, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer), keep=True,     # (keep masks: only with dropout on)
+                          fp8_out=f8)
+    if wproj is not None and run.fp8_seed:
+        _attn_fp8_out(run, okey, o, B, T, NH, H, NH * H)
     if wproj is not None:
         if fuse_ln is not None and nxt is not None and residual and o.shape[1] == x2d.shape[1] and _chain_ok(run, x2d, wproj):
             r = ops.block_chain_fwd(3, x2d.shape[0], x2d.shape[1], o=o, x=x2d, wproj=run.weights.pack(wproj), bproj=bproj, ln2w=fuse_ln[0],
@@ -342,7 +365,7 @@ def attn_fwd(run: Run, x2d: Tensor, ln_w: Optional[Tensor], ln_b: Optional[Tenso
             y = r["x1"]
             nxt.append((r["h2"], r["mean2"], r["rstd2"]))
         else:
-            y = linear_nt(run, o, wproj, torch.float32, fp8_site=f"{layer}.o", bias=bproj, dropout_p=run.p(p_proj),
+            y = linear_nt(run, o, wproj, torch.float32, fp8_site=f"{layer}.o", x8=getattr(o, "dg_fp8", None), bias=bproj, dropout_p=run.p(p_proj),
                           rng_state=run.rng, site=site_proj(layer), residual=x2d if residual else None)
     else:
         if residual:
@@ -369,7 +392,14 @@ def attn_bwd(run: Run, saved, dy: Tensor, ln_w: Optional[Tensor], wqkv: Tensor, 
         do = linear_dx(run, g, wproj, run.act, fp8_site=f"{layer}.g_proj")
     else:
         do = _as_act(run, dy)
-    dqkv = ops.attn_bwd(qkv, o, do, lse, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer))
+    gkey = f"{layer}.dqkv#attn"
+    f8 = _attn_fp8_out(run, gkey, None, B, T, NH, H, wqkv.shape[0]) if need_dx else None
+    if f8 is not None and run.weights.bwd8(wqkv)[0].shape[1] != wqkv.shape[0]:
+        f8 = None                                  # (linear_dx would not take the fp8 GEMM)
+    dqkv = ops.attn_bwd(qkv, o, do, lse, B, T, NH, H, H ** -0.5, run.p(p_attn), run.rng, site_attn(layer), fp8_out=f8,
+                        fp8_out_only=f8 is not None and run.fp8_only)
+    if need_dx and run.fp8_seed:
+        _attn_fp8_out(run, gkey, dqkv, B, T, NH, H, wqkv.shape[0])
     weight_grad(sink, keys["wqkv"], dqkv, h, wqkv.shape[0], wqkv.shape[1])
     if not need_dx:
         return None

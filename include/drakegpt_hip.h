@@ -45,7 +45,7 @@ extern "C" {
 #define DG_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
 #define DG_ERR_DTYPE (-3)
 
-#define DG_ABI_VERSION 19   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
+#define DG_ABI_VERSION 20   /* bump whenever a signature or struct of this header changes: the Python binding refuses a stale library */
 
 int dg_version(void);
 const char* dg_error_string(int code);
@@ -322,6 +322,29 @@ int dg_attn_bwd(const void* qkv, const void* out, const void* dout, const float*
                 void* dqkv, void* workspace, int64_t workspace_bytes, int B, int T, int NH, int H,
                 float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
                 int dtype, const void* keep_bits, int64_t keep_bits_bytes, void* stream);
+
+/* Precision "fp8" (round 3): the attention kernels leave their outputs a second time as fp8, so that the cast launches in front of
+ * the projection (o as e4m3: the x operand of `proj` and of its weight gradient -- ref: MultiHeadAttention3.proj,
+ * src/model_component.py:454) and in front of the QKV dX GEMM (dqkv as e5m2: its gradient operand and the dY of the QKV weight
+ * gradient -- ref: autograd through the packed query / key / value Linears, :392-393) disappear.  Delayed per-tensor scaling as in
+ * dg_fp8_quantize_delayed, with a history format of the kernels' own: hist3 = DG_ATTN_FP8_HIST floats per call site (16-byte
+ * aligned; three slots of 64 partial maxima, each partial on a 128-byte line of its own -- partial i of slot s is word
+ * (s * 64 + i) * 32) -- slot step % 3 (step = step_state[2]) collects this step's maxima by atomic max, slot (step + 2) % 3 holds
+ * last step's (the scale of this launch, *scale_inv = its inverse), slot (step + 1) % 3 is cleared for the next step; seed every
+ * partial with a just-in-time maximum.  q8: [B*T, NH*H] (forward) / [B*T, 3*NH*H] (backward), one byte per element, 16-byte aligned.  only8 (backward only): the
+ * bf16 dqkv is not written.  dg_attn_fp8_out_supported: 1 when the shape takes the MFMA kernels in their default forms (else cast). */
+#define DG_ATTN_FP8_HIST (3 * 64 * 32)
+typedef struct dg_attn_fp8_out {
+    void* q8; float* hist3; const uint32_t* step_state; float* scale_inv; int only8;
+} dg_attn_fp8_out;
+int dg_attn_fp8_out_supported(int B, int T, int NH, int H, int dtype);
+int dg_attn_fwd_fp8(const void* qkv, void* out, float* lse, int B, int T, int NH, int H,
+                    float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
+                    int dtype, void* keep_bits, int64_t keep_bits_bytes, const dg_attn_fp8_out* fp8, void* stream);
+int dg_attn_bwd_fp8(const void* qkv, const void* out, const void* dout, const float* lse,
+                    void* dqkv, void* workspace, int64_t workspace_bytes, int B, int T, int NH, int H,
+                    float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
+                    int dtype, const void* keep_bits, int64_t keep_bits_bytes, const dg_attn_fp8_out* fp8, void* stream);
 
 /* Single-query attention against a K/V cache for generate() -- ref: src/model.py:625-635 re-runs the
  * whole forward per new token; with the cache only the new position is computed.  qkv_cache:

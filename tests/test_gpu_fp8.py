@@ -447,6 +447,60 @@ def test_fp8_quantize_delayed_uses_last_steps_amax(dev):
     assert parts2[P:].max().item() == a1.item() and abs(s3.item() * (57344.0 / a2.item()) - 1.0) < 1e-6
 
 
+@pytest.mark.parametrize("B,T,NH,p", [(2, 256, 4, 0.1), (1, 1024, 2, 0.1), (3, 128, 2, 0.0)])
+def test_attention_kernels_leave_fp8_copies(dev, B, T, NH, p):
+    """dg_attn_fwd_fp8 / dg_attn_bwd_fp8: the bf16 outputs are those of the plain entry points bit for bit; the fp8 copies are the
+    saturating cast of those bf16 values with LAST step's maximum (history slot (step + 2) % 3); this step's maximum lands in slot
+    step % 3, slot (step + 1) % 3 is cleared; only8 leaves the same bytes and no bf16 dqkv.  ref: Head2.forward
+    src/model_component.py:392-405 (o feeds MultiHeadAttention3.proj, :454; dqkv feeds autograd of the packed QKV Linears)."""
+    from drakegpt_amd import ops
+    H = 64
+    assert ops.attn_fp8_out_supported(B, T, NH, H, torch.bfloat16)
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = torch.randn(B * T, 3 * NH * H, generator=g).bfloat16().to(dev)
+    dout = (torch.randn(B * T, NH * H, generator=g) * 0.3).bfloat16().to(dev)
+    for step in (6, 7, 8):
+        state = ops.new_rng_state(77, dev, step)
+        rng = state if p > 0 else None
+        o_ref, lse_ref = ops.attn_fwd(qkv, B, T, NH, H, H ** -0.5, p, rng, 5, keep=True)
+        d_ref = ops.attn_bwd(qkv, o_ref, dout, lse_ref, B, T, NH, H, H ** -0.5, p, rng, 5)
+        a_o, a_d = o_ref.float().abs().max(), d_ref.float().abs().max()
+        # forward: last step's maximum smaller than this tensor's -> some elements saturate
+        seed_o = (a_o * 0.37).reshape(1)
+        hist = ops.new_attn_fp8_history(seed_o)
+        hist.view(3, 64, 32)[(step + 1) % 3, :, 0] = 123.0                 # must be cleared
+        o, lse = ops.attn_fwd(qkv, B, T, NH, H, H ** -0.5, p, rng, 5, keep=True, fp8_out=(hist, state))
+        q8, sinv = o.dg_fp8
+        torch.cuda.synchronize()
+        assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref)
+        sc = torch.tensor(448.0) / seed_o.cpu()
+        want = (o_ref.cpu().float() * sc).clamp(-448, 448).to(E4)
+        assert torch.equal(q8.cpu().view(torch.uint8), want.view(torch.uint8))
+        assert (q8.cpu().float().abs() == 448).sum() > 0
+        assert abs(sinv.item() * sc.item() - 1.0) < 1e-6
+        h3 = hist.view(3, 64, 32)[:, :, 0].cpu()
+        assert h3[step % 3].max().item() == a_o.item()
+        assert (h3[(step + 1) % 3] == 0).all() and (h3[(step + 2) % 3] == seed_o.item()).all()
+        # backward, with and without the bf16 form
+        seed_d = (a_d * 1.5).reshape(1)
+        for only in (False, True):
+            hist = ops.new_attn_fp8_history(seed_d)
+            hist.view(3, 64, 32)[step % 3] = 0.0                           # (as the previous step leaves it)
+            d = ops.attn_bwd(qkv, o, dout, lse, B, T, NH, H, H ** -0.5, p, rng, 5, fp8_out=(hist, state), fp8_out_only=only)
+            d8, dsinv = d.dg_fp8
+            torch.cuda.synchronize()
+            if only:
+                assert getattr(d, "dg_unwritten", False)
+            else:
+                assert torch.equal(d, d_ref)
+            sc = torch.tensor(57344.0) / seed_d.cpu()
+            want = (d_ref.cpu().float() * sc).clamp(-57344, 57344).to(E5)
+            assert torch.equal(d8.cpu().view(torch.uint8), want.view(torch.uint8))
+            assert abs(dsinv.item() * sc.item() - 1.0) < 1e-6
+            h3 = hist.view(3, 64, 32)[:, :, 0].cpu()
+            assert h3[step % 3].max().item() == a_d.item() and (h3[(step + 1) % 3] == 0).all()
+
+
 def test_gpt2_medium_shape_fp8_engine_steps(dev):
     """BASELINE.json configs[4]: GPT-2-medium shape (V 50257, C 1024, T 1024, 16 heads, 24 layers), precision "fp8", B = 1.
     Two captured engine steps: loss finite and near ln V at init, falling after one AdamW step on the same batch; against the
@@ -478,7 +532,9 @@ def test_gpt2_medium_shape_fp8_engine_steps(dev):
         if prec == "fp8":
             # every Linear of every block, forward and dX operands (+ the input of the fp8 lm_head); round 3: + the two LayerNorm
             # launches per block that emit their output as e4m3 themselves (their own history format: one partial per workgroup)
-            assert sum(1 for k in eng.fp8_sites if not k.endswith("#ln")) == 8 * L + int(eng.fp8_head)
+            # and the two attention call sites per block whose fp8 copies leave the attention kernels (three-slot history)
+            assert sum(1 for k in eng.fp8_sites if "#" not in k) == 8 * L + int(eng.fp8_head)
+            assert sum(1 for k in eng.fp8_sites if k.endswith("#attn")) == 2 * L
             assert sum(1 for k in eng.fp8_sites if k.endswith("#ln")) == 2 * L
         grads = {k: v.detach().clone() for k, v in eng.named_grads().items()}
         l1 = eng.step().item()                                 # same batch again, after one AdamW step: a graph replay
