@@ -387,6 +387,8 @@ int main(int argc, char** argv) {
     run_tn<4, 4, 8>("8 waves of 64x64 (256x128 tile: halve the printed time per 128x128x64)", src, region, iters, out, sink);
     run_tn<4, 4, 8, true>("8 waves of 64x64, B fragments by ds_read_b128 from an X^T image", src, region, iters, out, sink);
     run_step<2, 4>("8 waves of 32x64", 8, src, region, row_stride, iters, out, sink);
+    run_step<4, 4>("8 waves of 64x64 (a 256x128 tile: twice the FLOP per step, halve the time to compare)", 8, src, region, row_stride, iters, out, sink);
+    run_step<2, 6>("8 waves of 32x96 (the 128x192 tile: 1.5x the FLOP per step)", 8, src, region, row_stride, iters, out, sink);
     if (argc > 1) return 0;
     for (int mode = 0; mode < 2; ++mode)
       for (int nreg : {32, 4})
