@@ -234,6 +234,13 @@ __global__ __launch_bounds__(CE_BLOCK) void cross_entropy_row_kernel(const TL* l
 // stores (the 2-byte-per-lane form of the generic kernel ran at half the rate of the fp32 one: 1240 us instead of 636 us for
 // M = 8192 rows of 50257).  ldl % 8 == 0 and a 16-byte aligned base; may run in place (dlogits == logits).
 #define CE_MAXC 7                     // 7 x 1024 x 8 = 57344 >= 53248
+// exp(x - mx) as ONE v_exp_f32 behind one fused multiply-add: exp2(x log2(e) - mx log2(e)).  expf() is ~12 instructions here (range
+// reduction, ldexp, the overflow / underflow selects) and this kernel evaluates it twice per logit: the instruction stream, not the
+// 1.65 GB, was what bounded it (~36 executed VALU instructions per logit, two thirds of them in the two exponentials).  The argument
+// is <= 0, results below 2^-126 flush to zero; relative error <= 2^-23 + |x - mx| 2^-24 log2(e) (2e-6 at x - mx = -20), three orders of
+// magnitude below the bf16 rounding of the gradient this kernel writes.  The fp32-logits kernels keep expf (the parity mode).
+#define CE_LOG2E 1.4426950408889634f
+__device__ __forceinline__ float ce_exp_fast(float x, float mxl) { return __builtin_amdgcn_exp2f(__builtin_fmaf(x, CE_LOG2E, -mxl)); }
 // The row stays in registers as the bf16 words it was loaded as (28 registers per thread instead of 56 fp32 values): at <= 64
 // registers TWO workgroups are resident per CU and one's loads run beside the other's stores (one resident workgroup
 // alternated between a load phase and a store phase: 570 us = 2.9 TB/s at M = 8192, V = 50257).  The exponentials are
@@ -272,6 +279,7 @@ __global__ __launch_bounds__(CE_BLOCK, 8) void cross_entropy_row_bf16_kernel(con
 #pragma unroll
     for (int k = 1; k < 16; ++k) mx = fmaxf(mx, red[k]);
     __syncthreads();
+    const float mxl = mx * CE_LOG2E;
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < CE_MAXC; ++j) {
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(CE_BLOCK, 8) void cross_entropy_row_bf16_kernel(con
         if (c < nchunk && c * 8 < V) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (c * 8 + e < V) s += expf((float)q[j][e] - mx);
+                if (c * 8 + e < V) s += ce_exp_fast((float)q[j][e], mxl);
         }
     }
     s = wave_sum(s);
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(CE_BLOCK, 8) void cross_entropy_row_bf16_kernel(con
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int i = c * 8 + e;
-                    gv[e] = i < V ? (expf((float)q[j][e] - mx) * inv - (i == (int)t ? 1.f : 0.f)) * grad_scale : 0.f;
+                    gv[e] = i < V ? (ce_exp_fast((float)q[j][e], mxl) * inv - (i == (int)t ? 1.f : 0.f)) * grad_scale : 0.f;
                     o[e] = (bf16_t)gv[e];
                 }
                 *(bf16x8*)(d + c * 8) = o;
