@@ -315,15 +315,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
         for (int ks = 0; ks < 4; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(imgK, ks, lane), qf[ks], S, 0, 0, 0);
         const int k0 = kt * TILE;
         const uint32_t wtile = wbase + (uint32_t)(k0 >> 1) * DG_WEYL;
+        // (round 3: two multiplies per score less -- the running maximum is taken on the raw scores and scaled once (sc > 0), the
+        // scale rides in the exponential's fused multiply-add, and the kept probabilities go into the P V product unscaled: 1 / (1 - p)
+        // multiplies the finished output row instead; 32 of the interior tile's 320 vector instructions)
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float sv = S[r] * sc;
-            if (DIAG && k0 + krow(r, hh) > qi) sv = -INFINITY;
-            S[r] = sv;
-            mx = fmaxf(mx, sv);
+            if (DIAG && k0 + krow(r, hh) > qi) S[r] = -INFINITY;
+            mx = fmaxf(mx, S[r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
         const float mn = fmaxf(m, mx);
         const float alpha = __builtin_amdgcn_exp2f(m - mn);
         m = mn;
@@ -331,13 +332,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
         unsigned long long km[16];                          // (KEEP) the sixteen compare masks of this tile
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {                   // registers r, r + 1 = adjacent keys = one hash pair
-            float e0 = __builtin_amdgcn_exp2f(S[r] - mn), e1 = __builtin_amdgcn_exp2f(S[r + 1] - mn);
+            float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], sc, -mn)), e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r + 1], sc, -mn));
             ps += e0 + e1;
             if (DROP) {
                 const uint32_t x = dg_hash_w(key, wtile + (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2)) * DG_WEYL);
                 const bool k0b = dg_keep_lo(x, p.thr), k1b = dg_keep_hi(x, p.thr);
-                e0 = k0b ? e0 * p.inv_keep : 0.f;
-                e1 = k1b ? e1 * p.inv_keep : 0.f;
+                e0 = k0b ? e0 : 0.f;
+                e1 = k1b ? e1 : 0.f;
                 if (KEEP) { km[r] = __builtin_amdgcn_ballot_w64(k0b); km[r + 1] = __builtin_amdgcn_ballot_w64(k1b); }
             }
             S[r] = e0; S[r + 1] = e1;
@@ -386,15 +387,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(AttnP p) {
     tile(std::true_type{}, qb);
     lsum += __shfl_xor(lsum, 32, 64);
     if (hh == 0 && qi < T) p.lse[bh * T + qi] = (m + log2f(lsum)) * (1.f / LOG2E);
+    const float onorm = (DROP ? p.inv_keep : 1.f) / lsum;
     if (F8) {
         // (the scale is fetched here, behind the tile loop: nothing of it lives across the loop, and the other waves of the SIMD cover the round trip)
         const float f8sc = attn_f8_begin(p, 448.f, lane, bh * p.nblk + blk);
         float am = 0.f;
-        store_T_acc<1>(imgK, O, 1.f / lsum, p.out_w + (int64_t)b * T * C + h * HD, C, q0, T, lane, p.q8 + (int64_t)b * T * C + h * HD, f8sc, &am,
+        store_T_acc<1>(imgK, O, onorm, p.out_w + (int64_t)b * T * C + h * HD, C, q0, T, lane, p.q8 + (int64_t)b * T * C + h * HD, f8sc, &am,
                        p.only8 != 0);
         attn_f8_end(p, am, lane, bh * p.nblk + blk);
     } else
-        store_T_acc(imgK, O, 1.f / lsum, p.out_w + (int64_t)b * T * C + h * HD, C, q0, T, lane);
+        store_T_acc(imgK, O, onorm, p.out_w + (int64_t)b * T * C + h * HD, C, q0, T, lane);
 }
 
 // =============================================================================================
