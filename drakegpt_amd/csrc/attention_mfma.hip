@@ -604,7 +604,9 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
     // fragment is parked in the wave's LDS slice instead (1 KB) and read back with the K fragments of each tile.
     char* imgQ0 = smem + wave * WAVE_LDS_DQ + 12288;
     *(bf16x8*)(imgQ0 + lane * 16) = qf[0];
-    const float L2 = p.lse_r[bh * T + (qi < T ? qi : T - 1)] * LOG2E;
+    // (query rows past the sequence end -- last, ragged block only -- get lse = +inf: every probability of theirs is exp2(-inf) = 0, so
+    // their P and dS come out as zeros without a select per score)
+    const float L2 = qi < T ? p.lse_r[bh * T + qi] * LOG2E : INFINITY;
     // delta_i = sum_d dO[i,d] O[i,d]: this lane holds half of row i of dO as MFMA fragments; dot it with the
     // matching half of O and add the other half-wave's part.  Written out for the dK/dV pass that follows.
     float dl = 0.f;
@@ -682,45 +684,54 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
         // score recomputation at all.  Staged through the V image (its MFMAs are done) so that the store is four full
         // 1 KB rows per instruction.
         constexpr bool emit = TM == 1, emit2 = TM == 2;
-        const bool rows_ok = q0 + TILE <= T;
         if (KB) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mkA), "+s"(mkB));
+        int qlim = kt == qb ? qi : 0x7fffffff;
+        asm volatile("" : "+v"(qlim));                             // (opaque: one loop body for interior and diagonal tiles, no peeled copy)
         bf16x8 p2[2];                                              // (tiles_mode 2) this lane's 16 signed probabilities
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             bf16x4 pv, dv;
             uint32_t xh = 0u;
+            // two scores at a time on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: one instruction per PAIR for the exponent's
+            // argument, dP keep/(1-p) - delta, P (...) and P keep/(1-p)): 4 of a pair's ~14 vector instructions
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * g + j;
-                const int kj = k0 + krow(r, hh);
-                float pr = __builtin_amdgcn_exp2f(S[r] * sc - L2);
-                if (kt == qb && kj > qi) pr = 0.f;
-                float kf = 1.f;
-                if (DROP && KB) {
-                    const uint32_t mlo = r < 8 ? mkA[2 * (r & 7)] : mkB[2 * (r & 7)], mhi = r < 8 ? mkA[2 * (r & 7) + 1] : mkB[2 * (r & 7) + 1];
-                    kf = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)mhi << 32) | mlo) ? p.inv_keep : 0.f;
-                } else if (DROP) {
-                    // Keys j, j + 1 of this run read the two fields of one hash word, but the word is hashed again for
-                    // each: holding it across the pair costs this kernel 43 spilled registers (measured, +3 us per
-                    // layer), so the pair saving is taken in the forward kernels only.  `zs` (a run-time zero) on
-                    // the odd key keeps the compiler from merging the two evaluations back together.
-                    const uint32_t w2 = wtile + (uint32_t)((j >> 1) + 4 * g) * DG_WEYL + ((j & 1) ? zs : 0u);
-                    xh = dg_hash_w(key, w2);
-                    kf = ((j & 1) ? dg_keep_hi(xh, p.thr) : dg_keep_lo(xh, p.thr)) ? p.inv_keep : 0.f;
+            for (int jp = 0; jp < 4; jp += 2) {
+                f32x2 kf2 = {1.f, 1.f};
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = jp + jj, r = 4 * g + j;
+                    if (DROP && KB) {
+                        const uint32_t mlo = r < 8 ? mkA[2 * (r & 7)] : mkB[2 * (r & 7)], mhi = r < 8 ? mkA[2 * (r & 7) + 1] : mkB[2 * (r & 7) + 1];
+                        kf2[jj] = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)mhi << 32) | mlo) ? p.inv_keep : 0.f;
+                    } else if (DROP) {
+                        // Keys j, j + 1 of this run read the two fields of one hash word, but the word is hashed again for
+                        // each: holding it across the pair costs this kernel 43 spilled registers (measured, +3 us per
+                        // layer), so the pair saving is taken in the forward kernels only.  `zs` (a run-time zero) on
+                        // the odd key keeps the compiler from merging the two evaluations back together.
+                        const uint32_t w2 = wtile + (uint32_t)((j >> 1) + 4 * g) * DG_WEYL + ((j & 1) ? zs : 0u);
+                        xh = dg_hash_w(key, w2);
+                        kf2[jj] = ((j & 1) ? dg_keep_hi(xh, p.thr) : dg_keep_lo(xh, p.thr)) ? p.inv_keep : 0.f;
+                    }
                 }
-                const float ds = pr * (dP[r] * kf - dl);
-                S[r] = ds;
-                pv[j] = (bf16_t)(pr * kf);
-                dv[j] = (bf16_t)ds;
+                const int r0 = 4 * g + jp;
+                const f32x2 arg = (f32x2){S[r0], S[r0 + 1]} * (f32x2){sc, sc} - (f32x2){L2, L2};
+                f32x2 pr2 = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+                if (k0 + krow(r0, hh) > qlim) pr2[0] = 0.f;         // (the diagonal tile: keys behind the query; qlim = INT_MAX elsewhere)
+                if (k0 + krow(r0 + 1, hh) > qlim) pr2[1] = 0.f;
+                const f32x2 ds2 = pr2 * ((f32x2){dP[r0], dP[r0 + 1]} * kf2 - (f32x2){dl, dl});
+                const f32x2 pk2 = pr2 * kf2;
+                S[r0] = ds2[0]; S[r0 + 1] = ds2[1];
+                pv[jp] = (bf16_t)pk2[0]; pv[jp + 1] = (bf16_t)pk2[1];
+                dv[jp] = (bf16_t)ds2[0]; dv[jp + 1] = (bf16_t)ds2[1];
                 // tiles_mode 2: only the probability travels, its sign bit says "dropped" (P >= 0 always); the dK/dV pass
                 // recomputes dP = dO V^T with four MFMAs and dS from it -- half the tile bytes, no LDS staging here
-                if (emit2) p2[g >> 1][4 * (g & 1) + j] = (bf16_t)((!rows_ok && qi >= T) ? 0.f : (kf != 0.f ? pr : -pr));
+                if (emit2) {
+                    p2[g >> 1][4 * (g & 1) + jp] = (bf16_t)(kf2[0] != 0.f ? pr2[0] : -pr2[0]);
+                    p2[g >> 1][4 * (g & 1) + jp + 1] = (bf16_t)(kf2[1] != 0.f ? pr2[1] : -pr2[1]);
+                }
             }
             if (emit) {
-                if (!rows_ok && qi >= T) {                         // query rows past the sequence end (last, ragged block only)
-                    pv = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-                    dv = pv;
-                }
                 // row = lane: the 16-byte chunk index is XOR-ed with the row so that the 32 lanes of a row-per-lane write do
                 // not all land on the same two banks (unswizzled this was 3.5 conflict cycles per LDS cycle in the PMC pass)
                 *(bf16x4*)(imgV + c * 128 + ((g ^ (c & 7)) << 4) + 8 * hh) = pv;
