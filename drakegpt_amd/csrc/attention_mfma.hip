@@ -156,6 +156,10 @@ __device__ __forceinline__ int off_row(int row, int ch) { return row * 128 + ((c
 // transposed-read image: a half-wave's 4 rows x 4 chunks land on 16 distinct 16-byte slots
 __device__ __forceinline__ int off_tr(int row, int ch) { return row * 128 + ((ch ^ (((row >> 1) & 1) << 2)) << 4); }
 
+// element offset of row gr at row stride ld inside one (batch) slab: both below 2^24 and the product below 2^32 (T * 3 C), so ONE
+// full-rate v_mul_u32_u24 instead of the quarter-rate 64-bit v_mad_u64_u32 the plain (int64) gr * ld compiles to -- four of them per
+// tile_load, two or three tile_loads per tile
+__device__ __forceinline__ uint32_t row_off(int gr, int64_t ld) { return __umul24((unsigned)gr, (unsigned)ld); }
 // global [rows][HD] tile (row stride ld elements) -> 4 x 16 B per lane.  Rows >= T read row T-1 again (finite data):
 // every consumer masks them (causal mask / `ok` / bounded stores), and a clamped index keeps the load unconditional --
 // the predicated form cost one exec-mask branch per load (368 basic blocks in the dK/dV kernel).
@@ -164,7 +168,7 @@ __device__ __forceinline__ void tile_load(u32x4 (&r)[4], const bf16_t* base, int
     for (int i = 0; i < 4; ++i) {
         const int c = lane + 64 * i, row = c >> 3, ch = c & 7;
         int gr = row0 + row; gr = gr < T ? gr : T - 1;
-        r[i] = *(const u32x4*)(base + (int64_t)gr * ld + ch * 8);
+        r[i] = *(const u32x4*)(base + row_off(gr, ld) + ch * 8);
     }
 }
 template <bool TR>
@@ -202,7 +206,7 @@ __device__ __forceinline__ void frags_global(bf16x8 (&f)[4], const bf16_t* base,
     const int hh = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        u32x4 v = *(const u32x4*)(base + (int64_t)gr * ld + 16 * ks + 8 * hh);
+        u32x4 v = *(const u32x4*)(base + row_off(gr, ld) + 16 * ks + 8 * hh);
         f[ks] = __builtin_bit_cast(bf16x8, v);
     }
 }
@@ -232,8 +236,8 @@ __device__ __forceinline__ void store_T_acc(char* img, const f32x16 (&acc)[2], f
         const int gr = row0 + row;
         u32x4 v = *(const u32x4*)(img + row * 128 + ((ch ^ (row & 7)) << 4));
         if (gr < T) {
-            if (!F8 || !only8) *(u32x4*)(base + (int64_t)gr * ld + ch * 8) = v;
-            if (F8) *amax = attn_f8_chunk<F8 == 2>(v, sc, *amax, base8 + (int64_t)gr * ld + ch * 8);
+            if (!F8 || !only8) *(u32x4*)(base + row_off(gr, ld) + ch * 8) = v;
+            if (F8) *amax = attn_f8_chunk<F8 == 2>(v, sc, *amax, base8 + row_off(gr, ld) + ch * 8);
         }
     }
 }
@@ -254,8 +258,8 @@ __device__ __forceinline__ void store_N_acc(char* img, const f32x16 (&acc)[2], f
         const int gr = row0 + row;
         u32x4 v = *(const u32x4*)(img + row * 128 + ch * 16);
         if (gr < T) {
-            if (!F8 || !only8) *(u32x4*)(base + (int64_t)gr * ld + ch * 8) = v;
-            if (F8) *amax = attn_f8_chunk<F8 == 2>(v, sc, *amax, base8 + (int64_t)gr * ld + ch * 8);
+            if (!F8 || !only8) *(u32x4*)(base + row_off(gr, ld) + ch * 8) = v;
+            if (F8) *amax = attn_f8_chunk<F8 == 2>(v, sc, *amax, base8 + row_off(gr, ld) + ch * 8);
         }
     }
 }
@@ -461,8 +465,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma2_kernel(AttnP p) {
         for (int i = 0; i < 2; ++i) {
             const int cc = tid + 256 * i, row = cc >> 3, ch = cc & 7;
             int gr = it * 64 + row; gr = gr < T ? gr : T - 1;
-            rk[i] = *(const u32x4*)(Kb + (int64_t)gr * ld + ch * 8);
-            rv[i] = *(const u32x4*)(Vb + (int64_t)gr * ld + ch * 8);
+            rk[i] = *(const u32x4*)(Kb + row_off(gr, ld) + ch * 8);
+            rv[i] = *(const u32x4*)(Vb + row_off(gr, ld) + ch * 8);
         }
     };
     auto store2 = [&](char* buf) {
@@ -900,7 +904,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma_kernel(AttnP p) {
 // =============================================================================================
 bool dg_attn_mfma_supported(int B, int T, int NH, int H) {
     // (T even: a lane's adjacent keys then form the element pairs that share a dropout hash)
-    return H == HD && B > 0 && T > 0 && T % 2 == 0 && NH > 0 && (int64_t)B * NH * T * T < ((int64_t)1 << 32);
+    // (row offsets inside a batch slab are 24 x 24 -> 32-bit products: row_off)
+    return H == HD && B > 0 && T > 0 && T % 2 == 0 && NH > 0 && (int64_t)B * NH * T * T < ((int64_t)1 << 32) &&
+           T < (1 << 24) && 3 * (int64_t)NH * HD < (1 << 24) && (int64_t)T * 3 * NH * HD < ((int64_t)1 << 32);
 }
 
 

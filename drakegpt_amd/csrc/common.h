@@ -50,14 +50,17 @@ __host__ __device__ inline uint32_t dg_drop_threshold(float p) {
     return (uint32_t)t;
 }
 // The pair hash is a Weyl step ((idx >> 1) * golden ratio, which callers can also form incrementally with adds), one
-// xorshift32 round and ONE multiply (v_mul_lo_u32 is a quarter-rate instruction); both 16-bit halves of the product depend
+// xorshift32 round and ONE 24-bit multiply; both 16-bit halves of the product depend
 // on every input bit through the xorshift (measured keep rate / lag correlations / row and column dispersion / in-pair
 // correlation: oracle/rng_ref.py restates it, tests/test_host_logic.py checks the statistics).
 #define DG_WEYL 0x9E3779B1U
 __device__ __forceinline__ uint32_t dg_hash_w(uint32_t key, uint32_t w2) {               // w2 = (idx >> 1) * DG_WEYL
     uint32_t x = key ^ w2;
     x ^= x >> 17; x ^= x << 11; x ^= x >> 13;
-    x *= 0x7feb352dU;
+    // 24 x 24 -> low 32 bits (v_mul_u32_u24, a full-rate instruction; v_mul_lo_u32 issues at a quarter of that rate and was ~15 % of
+    // the forward attention tile's issue cycles): the product's low 24 bits are those of the 32-bit multiply it replaces, bits
+    // 24..31 now come from the middle of a 48-bit product (every one of the 24 input bits reaches them)
+    x = __umul24(x, 0xeb352dU);
     return x;
 }
 __device__ __forceinline__ bool dg_keep_lo(uint32_t x, uint32_t thr) { return (x & 0xFFFFu) >= thr; }   // element 2i

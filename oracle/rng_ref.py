@@ -38,12 +38,12 @@ def threshold(p: float) -> int:
 
 
 def element_hash(key: int, idx: np.ndarray) -> np.ndarray:
-    """dg_hash_w in common.h on the PAIR index idx: Weyl step, one xorshift32 round, one multiply."""
+    """dg_hash_w in common.h on the PAIR index idx: Weyl step, one xorshift32 round, one 24 x 24-bit multiply (low 32 bits)."""
     x = np.uint64(key) ^ ((idx.astype(np.uint64) * np.uint64(0x9E3779B1)) & _M32)
     x ^= x >> np.uint64(17)
     x ^= (x << np.uint64(11)) & _M32
     x ^= x >> np.uint64(13)
-    return (x * np.uint64(0x7FEB352D)) & _M32
+    return ((x & np.uint64(0xFFFFFF)) * np.uint64(0xEB352D)) & _M32
 
 
 def keep_mask(seed: int, step: int, site: int, p: float, n: int) -> np.ndarray:

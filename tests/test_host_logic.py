@@ -131,8 +131,12 @@ def test_dropout_hash_reference_properties():
     assert 0.93 < rows.var() / (256 * 0.2 * 0.8) < 1.07
     # two elements share one 32-bit hash (low / high 16 bits): no correlation inside a pair, columns dispersed too
     assert abs(np.corrcoef(k[0::2], k[1::2])[0, 1]) < 4e-3
-    cols = k.reshape(-1, 256).mean(0)
-    assert 0.8 < cols.var() / (0.2 * 0.8 / 8192) < 1.25
+    # (per key the ratio of 256 column means scatters by ~ sqrt(2 / 255) = 9 %: the bound is on the mean over several keys)
+    ratios = []
+    for seed, step, site in ((7, 3, 5), (1, 0, 0), (99, 500, 2), (12345, 77777, 13), (3, 9, 27), (8, 1, 6)):
+        kk = k if (seed, step, site) == (7, 3, 5) else rng_ref.keep_mask(seed, step, site, 0.2, 256 * 8192).astype(np.float64)
+        ratios.append(kk.reshape(-1, 256).mean(0).var() / (0.2 * 0.8 / 8192))
+    assert all(0.7 < r < 1.35 for r in ratios) and 0.9 < sum(ratios) / len(ratios) < 1.1, ratios
 
 
 # ------------------------------------------------------------------------------------------------ data side
