@@ -29,6 +29,10 @@ from __future__ import annotations
 import argparse
 import json
 import os
+
+# multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC: RCCL fails with
+# hipIpcGetMemHandle: invalid argument otherwise); the driver's environment exports it, this is the belt to its braces
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import sys
 import time
 
