@@ -983,6 +983,100 @@ __device__ __forceinline__ void attn_bwd_dkv_tiles_body(const AttnP& p) {
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_tiles_kernel(AttnP p) { attn_bwd_dkv_tiles_body<false>(p); }
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_tiles_f8_kernel(AttnP p) { attn_bwd_dkv_tiles_body<true>(p); }
 
+// The same pass with the Q and dO tiles SHARED by the four waves of a workgroup (round 3; the balanced block orders only: there the
+// four key blocks of a workgroup belong to one (batch, head), so every query tile one of them needs, the others need too).  In the
+// kernel above each wave fetches and stages its own copy of Q and dO for every tile -- measured by ablation at the GPT-2-medium
+// shape (B = 8): 99.8 us per layer, 63.7 us with those loads left out, 51.7 us with the P | dS loads left out instead.  Here a tile
+// of Q / dO is fetched ONCE per workgroup, a quarter per wave (2 x 16 B per lane instead of 8 x), into a double-buffered shared
+// transposed-read image, behind one workgroup barrier per query tile (a buffer is rewritten two barriers after it was read); the
+// P | dS tile stays private.  The shared loop runs over the query tiles of the workgroup's LOWEST key block; a wave whose key block
+// starts later only helps loading until its own first tile.  20 KB of LDS less per workgroup, 24 prefetch registers less per lane.
+#define WG_LDS_DKVS (4 * 4096 + 2 * 8192)
+template <bool F8>
+__device__ __forceinline__ void attn_bwd_dkv_tiles_shared_body(const AttnP& p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int64_t bh; int blk; bool valid;
+    attn_item(p, wave, bh, blk, valid);
+    if (!valid) return;                                        // (uniform per workgroup in the balanced orders)
+    const int kb = p.nblk - 1 - blk;
+    int kmin = kb;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        int64_t bh_w; int blk_w; bool v_w;
+        attn_item(p, w, bh_w, blk_w, v_w);
+        const int kw = p.nblk - 1 - blk_w;
+        kmin = kw < kmin ? kw : kmin;
+    }
+    char* imgP = smem + wave * 4096;                           // private: [32 q][P 32 | dS 32]
+    char* shared = smem + 4 * 4096;                            // [2 buffers][Q^T image 4 KB | dO^T image 4 KB]
+    const int h = (int)(bh % p.NH), b = (int)(bh / p.NH);
+    const int T = p.T, C = p.NH * HD;
+    const int64_t ld = 3 * (int64_t)C;
+    const bf16_t* Qb = p.qkv + (int64_t)b * T * ld + h * HD;
+    const bf16_t* dOb = p.dout + (int64_t)b * T * C + h * HD;
+    const int k0 = kb * TILE;
+    f32x16 dK[2], dV[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dK[0][i] = 0.f; dK[1][i] = 0.f; dV[0][i] = 0.f; dV[1][i] = 0.f; }
+    auto load_pt = [&](u32x4 (&r)[4], int qt) {
+        const char* tb = p.tiles + attn_tile_index(p, bh, qt, kb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *(const u32x4*)(tb + (lane + 64 * i) * 16);
+    };
+    // this wave's quarter of a [32 rows][128 B] tile: chunk c = 64 wave + lane -> row c >> 3 (rows 8 wave .. 8 wave + 7), 16-byte chunk c & 7
+    const int qrow = 8 * wave + (lane >> 3), qch = lane & 7;
+    auto load_q4 = [&](u32x4& rq, u32x4& rg, int qt) {
+        int gr = qt * TILE + qrow; gr = gr < T ? gr : T - 1;   // clamped like tile_load
+        rq = *(const u32x4*)(Qb + row_off(gr, ld) + qch * 8);
+        rg = *(const u32x4*)(dOb + row_off(gr, C) + qch * 8);
+    };
+    u32x4 rp[4], rq, rg;
+    load_q4(rq, rg, kmin);
+    if (kb == kmin) load_pt(rp, kb);
+    for (int qt = kmin; qt < p.nblk; ++qt) {
+        char* imgQt = shared + ((qt - kmin) & 1) * 8192;
+        char* imgGt = imgQt + 4096;
+        const bool active = qt >= kb;                          // (wave-uniform)
+        *(u32x4*)(imgQt + off_tr(qrow, qch)) = rq;
+        *(u32x4*)(imgGt + off_tr(qrow, qch)) = rg;
+        if (active) tile_store<true>(imgP, rp, lane);
+        if (qt + 1 < p.nblk) {
+            load_q4(rq, rg, qt + 1);
+            if (qt + 1 >= kb) load_pt(rp, qt + 1);
+        }
+        __syncthreads();                                       // the shared tile is complete (and the one before it fully read)
+        if (active) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = frag_tr(imgP, 0, s, lane), df = frag_tr(imgP, 1, s, lane);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag_tr(imgGt, dt, s, lane), dV[dt], 0, 0, 0);
+                    dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, frag_tr(imgQt, dt, s, lane), dK[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    bf16_t* dKb = p.dqkv + (int64_t)b * T * ld + C + h * HD;
+    if (F8) {
+        uint8_t* dK8 = p.q8 + (int64_t)b * T * ld + C + h * HD;
+        const float f8sc = attn_f8_begin(p, 57344.f, lane, bh * p.nblk + blk);
+        float am = 0.f;
+        store_N_acc<2>(imgP, dK, p.scale, dKb, ld, k0, T, lane, dK8, f8sc, &am, p.only8 != 0);
+        __builtin_amdgcn_wave_barrier();
+        store_N_acc<2>(imgP, dV, 1.f, dKb + C, ld, k0, T, lane, dK8 + C, f8sc, &am, p.only8 != 0);
+        attn_f8_end(p, am, lane, bh * p.nblk + blk);
+        return;
+    }
+    store_N_acc(imgP, dK, p.scale, dKb, ld, k0, T, lane);
+    __builtin_amdgcn_wave_barrier();
+    store_N_acc(imgP, dV, 1.f, dKb + C, ld, k0, T, lane);
+}
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_tiles_shared_kernel(AttnP p) { attn_bwd_dkv_tiles_shared_body<false>(p); }
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_tiles_shared_f8_kernel(AttnP p) { attn_bwd_dkv_tiles_shared_body<true>(p); }
+
 // =============================================================================================
 // dK/dV from the SIGNED-PROBABILITY tiles of the dQ pass (tiles_mode 2): per 32 x 32 tile the dQ pass leaves 2 KB -- every lane's 16
 // probabilities exactly as it holds them (lane = query, registers = keys), negative where the element was dropped -- instead of
@@ -1128,6 +1222,11 @@ int64_t dg_attn_mfma_keep_bytes(int B, int T, int NH) {
     return (int64_t)B * NH * (nblk * (nblk + 1) / 2) * 128;
 }
 
+// the dK/dV tile pass with shared Q / dO tiles: the balanced block orders (a workgroup = four key blocks of ONE (batch, head)); DG_ATTN_DKV_SHARED=0 = the per-wave form (A/B)
+static bool attn_dkv_shared(const AttnP& p) {
+    static const int mode = [] { const char* e = getenv("DG_ATTN_DKV_SHARED"); return e ? atoi(e) : 1; }();
+    return mode != 0 && p.balance != 0;
+}
 static int attn_tile_mode() {
     static const int tile_mode = [] { const char* e = getenv("DG_ATTN_TILES"); return e ? atoi(e) : 1; }();   // 1 = P | dS tiles (default), 2 = signed P tiles (measured slower), 0 = recompute in the dK/dV pass
     return tile_mode;
@@ -1217,7 +1316,8 @@ int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const f
         }
         DG_LAUNCH_CHECK();
         p.sinv = nullptr;                                 // (written by the dQ pass)
-        hipLaunchKernelGGL(attn_bwd_dkv_tiles_f8_kernel, grid, block, 4 * WAVE_LDS_DKVT, s, p);
+        if (attn_dkv_shared(p)) hipLaunchKernelGGL(attn_bwd_dkv_tiles_shared_f8_kernel, grid, block, WG_LDS_DKVS, s, p);
+        else hipLaunchKernelGGL(attn_bwd_dkv_tiles_f8_kernel, grid, block, 4 * WAVE_LDS_DKVT, s, p);
         DG_LAUNCH_CHECK();
         return DG_OK;
     }
@@ -1236,6 +1336,7 @@ int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const f
 #undef DQ_LAUNCH
     DG_LAUNCH_CHECK();
     if (tm == 2) hipLaunchKernelGGL(attn_bwd_dkv_ptiles_kernel, grid, block, 4 * WAVE_LDS_DKVP, s, p);
+    else if (p.tiles && attn_dkv_shared(p)) hipLaunchKernelGGL(attn_bwd_dkv_tiles_shared_kernel, grid, block, WG_LDS_DKVS, s, p);
     else if (p.tiles) hipLaunchKernelGGL(attn_bwd_dkv_tiles_kernel, grid, block, 4 * WAVE_LDS_DKVT, s, p);
     else if (p.drop) hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, grid, block, 4 * WAVE_LDS_DKV, s, p);
     else hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<false>, grid, block, 4 * WAVE_LDS_DKV, s, p);
