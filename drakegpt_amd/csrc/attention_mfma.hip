@@ -578,7 +578,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma2_kernel(AttnP p) {
 // TM: what the pass leaves behind for the dK/dV pass -- 0 nothing, 1 the [32 q][P | dS] tiles, 2 the signed probabilities only
 // KB: the keep decisions come as wave masks from the forward pass (AttnP::keep) instead of being hashed again
 // F8: dQ also as e5m2 into the fp8 copy of dqkv (AttnP::q8 ...; the dK/dV pass adds its two thirds under the same history)
-template <bool DROP, int TM, bool KB = false, bool F8 = false>      // dropout on the probabilities (compile-time: no per-element uniform branch)
+// SH (round 3; the balanced block orders, where a workgroup's four query blocks belong to one (batch, head)): the K / V tiles are
+// fetched ONCE per workgroup -- a quarter per wave -- into double-buffered shared images (K rows, K transposed-read, V rows) behind one
+// workgroup barrier per key tile, as in attn_bwd_dkv_tiles_shared_kernel; the loop runs to the workgroup's LAST query block and a
+// wave whose own block is finished only helps loading.  The P | dS staging area and the parked Q fragment stay private.
+#define WG_LDS_DQS (4 * 5120 + 2 * 12288)
+template <bool DROP, int TM, bool KB = false, bool F8 = false, bool SH = false>      // dropout on the probabilities (compile-time: no per-element uniform branch)
 __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block, pointers and loop bounds live in SGPRs
@@ -588,7 +593,17 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
     char* imgK = smem + wave * WAVE_LDS_DQ;      // row image of K
     char* imgKt = imgK + 4096;                   // transposed-read image of K
     char* imgV = imgK + 8192;                    // row image of V
+    char* imgE = SH ? smem + wave * 5120 : imgV; // staging area of the P | dS tile (per-wave form: the V image, whose MFMAs are done by then)
     const int qb = p.balance ? blk : p.nblk - 1 - blk;
+    int qmax = qb;                               // (SH) the workgroup's last query block
+    if (SH) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            int64_t bh_w; int blk_w; bool v_w;
+            attn_item(p, w, bh_w, blk_w, v_w);
+            qmax = blk_w > qmax ? blk_w : qmax;
+        }
+    }
     const int h = (int)(bh % p.NH), b = (int)(bh / p.NH);
     const int T = p.T, C = p.NH * HD;
     const int64_t ld = 3 * (int64_t)C;
@@ -606,7 +621,7 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
     // at the top of every tile: a scratch load is a vector-memory operation, `vmcnt` counts in order, so its `s_waitcnt vmcnt(0)`
     // also waited for the NEXT tile's K / V prefetch issued just before it -- a full global round trip exposed per tile.  The
     // fragment is parked in the wave's LDS slice instead (1 KB) and read back with the K fragments of each tile.
-    char* imgQ0 = smem + wave * WAVE_LDS_DQ + 12288;
+    char* imgQ0 = SH ? smem + wave * 5120 + 4096 : smem + wave * WAVE_LDS_DQ + 12288;
     *(bf16x8*)(imgQ0 + lane * 16) = qf[0];
     // (query rows past the sequence end -- last, ragged block only -- get lse = +inf: every probability of theirs is exp2(-inf) = 0, so
     // their P and dS come out as zeros without a select per score)
@@ -633,8 +648,18 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
     const uint32_t zs = p.thr >> 16;               // thr <= 0xFFFF: always 0, but not to the compiler (see the hash below)
 
     u32x4 rk[4], rv[4];
-    tile_load(rk, Kb, ld, 0, T, lane);
-    tile_load(rv, Vb, ld, 0, T, lane);
+    // (SH) this wave's quarter of a [32 rows][128 B] tile: rows 8 wave .. 8 wave + 7, 16-byte chunk lane & 7; kept in rk[0] / rv[0]
+    const int srow = 8 * wave + (lane >> 3), sch = lane & 7;
+    auto load_q4 = [&](int kt) {
+        int gr = kt * TILE + srow; gr = gr < T ? gr : T - 1;   // clamped like tile_load
+        rk[0] = *(const u32x4*)(Kb + row_off(gr, ld) + sch * 8);
+        rv[0] = *(const u32x4*)(Vb + row_off(gr, ld) + sch * 8);
+    };
+    if (SH) load_q4(0);
+    else {
+        tile_load(rk, Kb, ld, 0, T, lane);
+        tile_load(rv, Vb, ld, 0, T, lane);
+    }
     unsigned long long st_prev = 0, st_acc[5] = {0, 0, 0, 0, 0};
     const bool st_on = p.stamps != nullptr && wave == 0;          // (wave-uniform)
     auto stamp = [&](int k) {
@@ -645,7 +670,13 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
         }
     };
     stamp(-1);
-    for (int kt = 0; kt <= qb; ++kt) {
+    for (int kt = 0; kt <= (SH ? qmax : qb); ++kt) {
+        const bool active = !SH || kt <= qb;                      // (wave-uniform)
+        if (SH) {
+            imgK = smem + 4 * 5120 + (kt & 1) * 12288;
+            imgKt = imgK + 4096;
+            imgV = imgK + 8192;
+        }
         // LDS / global addresses are recomputed from the lane id every iteration (opaque to the optimiser) instead of being
         // hoisted into ~20 loop-invariant VGPRs: the kernel wants 186-219 VGPRs otherwise, and at three workgroups per CU
         // (168) the overflow went to scratch (no-dropout variant: 68 spilled registers, 65 -> 55 us for the backward pair).
@@ -656,20 +687,29 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
         // and turns a plain load into eight vector loads (32 VGPRs, all spilled) + readfirstlanes.
         typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
         u32x16 mkA, mkB;
-        if (KB) {
+        if (KB && active) {
             const unsigned long long a = (unsigned long long)(p.keep + attn_keep_index(p, bh, qb, kt) * 16);
             const uint32_t alo = __builtin_amdgcn_readfirstlane((uint32_t)a), ahi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
             const unsigned long long ua = ((unsigned long long)ahi << 32) | alo;
             asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(mkA), "=&s"(mkB) : "s"(ua) : "memory");
         }
-        tile_store<false>(imgK, rk, ln);
-        tile_store<true>(imgKt, rk, ln);
-        tile_store<false>(imgV, rv, ln);
-        if (kt < qb) {
-            tile_load(rk, Kb, ld, (kt + 1) * TILE, T, ln);
-            tile_load(rv, Vb, ld, (kt + 1) * TILE, T, ln);
+        if (SH) {
+            *(u32x4*)(imgK + off_row(srow, sch)) = rk[0];
+            *(u32x4*)(imgKt + off_tr(srow, sch)) = rk[0];
+            *(u32x4*)(imgV + off_row(srow, sch)) = rv[0];
+            if (kt < qmax) load_q4(kt + 1);
+            __syncthreads();                                      // the shared tile is complete (and the one before it fully read)
+            if (!active) continue;
+        } else {
+            tile_store<false>(imgK, rk, ln);
+            tile_store<true>(imgKt, rk, ln);
+            tile_store<false>(imgV, rv, ln);
+            if (kt < qb) {
+                tile_load(rk, Kb, ld, (kt + 1) * TILE, T, ln);
+                tile_load(rv, Vb, ld, (kt + 1) * TILE, T, ln);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
         stamp(0);
         f32x16 S, dP;
 #pragma unroll
@@ -738,8 +778,8 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
             if (emit) {
                 // row = lane: the 16-byte chunk index is XOR-ed with the row so that the 32 lanes of a row-per-lane write do
                 // not all land on the same two banks (unswizzled this was 3.5 conflict cycles per LDS cycle in the PMC pass)
-                *(bf16x4*)(imgV + c * 128 + ((g ^ (c & 7)) << 4) + 8 * hh) = pv;
-                *(bf16x4*)(imgV + c * 128 + (((4 + g) ^ (c & 7)) << 4) + 8 * hh) = dv;
+                *(bf16x4*)(imgE + c * 128 + ((g ^ (c & 7)) << 4) + 8 * hh) = pv;
+                *(bf16x4*)(imgE + c * 128 + (((4 + g) ^ (c & 7)) << 4) + 8 * hh) = dv;
             }
             // (KB) without the hash chains to order it the scheduler interleaves all sixteen scores and spills 34-51 registers: one
             // group of four at a time
@@ -752,7 +792,7 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int cc = ln + 64 * i, row = cc >> 3, ch = cc & 7;
-                *(u32x4*)(tb + cc * 16) = *(const u32x4*)(imgV + row * 128 + ((ch ^ (row & 7)) << 4));
+                *(u32x4*)(tb + cc * 16) = *(const u32x4*)(imgE + row * 128 + ((ch ^ (row & 7)) << 4));
             }
         }
         if (emit2) {
@@ -779,11 +819,11 @@ __global__ __launch_bounds__(256, DROP ? 3 : 2) void attn_bwd_dq_mfma_kernel(Att
     if (F8) {
         const float f8sc = attn_f8_begin(p, 57344.f, lane, bh * p.nblk + blk);
         float am = 0.f;
-        store_T_acc<2>(imgK, dQ, p.scale, p.dqkv + (int64_t)b * T * ld + h * HD, ld, q0, T, lane, p.q8 + (int64_t)b * T * ld + h * HD, f8sc, &am,
+        store_T_acc<2>(SH ? imgE : imgK, dQ, p.scale, p.dqkv + (int64_t)b * T * ld + h * HD, ld, q0, T, lane, p.q8 + (int64_t)b * T * ld + h * HD, f8sc, &am,
                        p.only8 != 0);
         attn_f8_end(p, am, lane, bh * p.nblk + blk);
     } else
-        store_T_acc(imgK, dQ, p.scale, p.dqkv + (int64_t)b * T * ld + h * HD, ld, q0, T, lane);
+        store_T_acc(SH ? imgE : imgK, dQ, p.scale, p.dqkv + (int64_t)b * T * ld + h * HD, ld, q0, T, lane);
 }
 
 // =============================================================================================
@@ -1211,7 +1251,10 @@ static void fill(AttnP& p, int B, int T, int NH, float scale, float dp, const ui
     p.balance = (mode != 0 && p.nblk % 4 == 0) ? 1 : 0;
     // heavy-first order when the launch is more than one residency (three 256-thread workgroups per CU); DG_ATTN_BALANCE=1 keeps the
     // equal-cost order everywhere (A/B)
-    if (p.balance && mode != 1 && (int64_t)B * NH * (p.nblk / 4) > (int64_t)3 * ncu * 11 / 10) p.balance = 2;
+    // ... and from 16 blocks on (T >= 512) at any size: with the K / V and Q / dO tiles shared by a workgroup's waves (round 3) the
+    // consecutive blocks of this order beat the equal-cost pairs at one residency too (GPT-2-small B = 8: 11.75 / 11.65 -> 11.66 /
+    // 11.56 ms; no difference at the headline shape's 8 blocks).  (mode 3: heavy first always -- A/B)
+    if (p.balance && mode != 1 && ((int64_t)B * NH * (p.nblk / 4) > (int64_t)3 * ncu * 11 / 10 || p.nblk >= 16 || mode == 3)) p.balance = 2;
     p.rot_div = ncu;
     static const int xcd = [] { const char* e = getenv("DG_ATTN_XCD"); return e ? atoi(e) : 1; }();   // 0 = plain blockIdx order (A/B runs)
     p.xcd = xcd;
@@ -1226,6 +1269,14 @@ int64_t dg_attn_mfma_keep_bytes(int B, int T, int NH) {
 static bool attn_dkv_shared(const AttnP& p) {
     static const int mode = [] { const char* e = getenv("DG_ATTN_DKV_SHARED"); return e ? atoi(e) : 1; }();
     return mode != 0 && p.balance != 0;
+}
+// the dQ pass with shared K / V tiles: the heavy-first order only, where a workgroup's four query blocks are CONSECUTIVE (the shared
+// loop runs to the last of them: three idle tiles at most).  In the equal-cost order (blocks j and nblk - 1 - j in one workgroup) the
+// short waves would sit at the barriers of the long ones: measured slower at the headline shape (2.326 / 2.336 -> 2.344 / 2.342 ms) and
+// no better at GPT-2-small B = 8.  DG_ATTN_DQ_SHARED=0 = the per-wave form everywhere, 2 = shared in both balanced orders (A/B).
+static bool attn_dq_shared(const AttnP& p) {
+    static const int mode = [] { const char* e = getenv("DG_ATTN_DQ_SHARED"); return e ? atoi(e) : 1; }();
+    return mode == 2 ? p.balance != 0 : (mode != 0 && p.balance == 2);
 }
 static int attn_tile_mode() {
     static const int tile_mode = [] { const char* e = getenv("DG_ATTN_TILES"); return e ? atoi(e) : 1; }();   // 1 = P | dS tiles (default), 2 = signed P tiles (measured slower), 0 = recompute in the dK/dV pass
@@ -1308,11 +1359,15 @@ int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const f
         // dqkv also as e5m2: dQ from the dQ pass, dK / dV from the tile pass, one history, one scale
         if (!dg_attn_mfma_f8_supported() || tm != 1) return DG_ERR_ARG;
         if (int rc = attn_f8_fill(p, f8)) return rc;
-        if (p.drop && p.keep) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, true, true>), grid, block, 4 * WAVE_LDS_DQ, s, p);
-        else {
+        const bool sh = attn_dq_shared(p);
+        if (p.drop && p.keep) {
+            if (sh) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, true, true, true>), grid, block, WG_LDS_DQS, s, p);
+            else hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, true, true>), grid, block, 4 * WAVE_LDS_DQ, s, p);
+        } else {
             AttnP q = p;
             if (!p.drop) { q.thr = 0u; q.inv_keep = 1.f; q.rng = (const uint32_t*)qkv; q.site = 0; }     // (as below: the DROP code with a threshold of 0)
-            hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, false, true>), grid, block, 4 * WAVE_LDS_DQ, s, q);
+            if (sh) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, false, true, true>), grid, block, WG_LDS_DQS, s, q);
+            else hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, false, true>), grid, block, 4 * WAVE_LDS_DQ, s, q);
         }
         DG_LAUNCH_CHECK();
         p.sinv = nullptr;                                 // (written by the dQ pass)
@@ -1325,13 +1380,19 @@ int dg_attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const f
         if (tm == 2) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DROP_, 2>), grid, block, 4 * WAVE_LDS_DQ, s, Q_); \
         else if (tm == 1) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DROP_, 1>), grid, block, 4 * WAVE_LDS_DQ, s, Q_); \
         else hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<DROP_, 0>), grid, block, 4 * WAVE_LDS_DQ, s, Q_); } while (0)
-    if (p.drop && p.keep && tm == 1) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, true>), grid, block, 4 * WAVE_LDS_DQ, s, p);
-    else if (p.drop) DQ_LAUNCH(true, p);
-    else if (nodrop_variant) DQ_LAUNCH(false, p);
+    const bool sh = tm == 1 && attn_dq_shared(p);
+    if (p.drop && p.keep && tm == 1) {
+        if (sh) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, true, false, true>), grid, block, WG_LDS_DQS, s, p);
+        else hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, true>), grid, block, 4 * WAVE_LDS_DQ, s, p);
+    } else if (p.drop) {
+        if (sh) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, false, false, true>), grid, block, WG_LDS_DQS, s, p);
+        else DQ_LAUNCH(true, p);
+    } else if (nodrop_variant) DQ_LAUNCH(false, p);
     else {
         AttnP q = p;
         q.thr = 0u; q.inv_keep = 1.f; q.rng = (const uint32_t*)qkv; q.site = 0;     // (qkv: at least 384 readable bytes)
-        DQ_LAUNCH(true, q);
+        if (sh) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<true, 1, false, false, true>), grid, block, WG_LDS_DQS, s, q);
+        else DQ_LAUNCH(true, q);
     }
 #undef DQ_LAUNCH
     DG_LAUNCH_CHECK();
