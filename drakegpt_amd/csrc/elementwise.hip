@@ -65,27 +65,33 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ idx, const float* _
         }
         off = bs.offsets + (int64_t)row * bs.B;
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t m = i / cv;
-        int c = (int)(i % cv) * VEC;
-        int t = (int)(m % T);
+    (void)total;
+    // A WAVE per row (round 3): the row index, its position t = m % T, its batch row m / T and the token id are wave-uniform -- one
+    // scalar division per row, where the flat form (one work item per 16 bytes) ran four 64-BIT integer divisions per work item:
+    // ~100 vector instructions each, for a kernel that moves 16 bytes per item.
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t m = wave0; m < M; m += nwaves) {
+        const uint32_t mu = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);          // (M < 2^31 rows)
+        const uint32_t bq = mu / (uint32_t)T;
+        const int t = (int)(mu - bq * (uint32_t)T);
         int64_t v;
         if (GATHER) {
             // offsets come from randint(n - T): o + 1 <= n - 1.  Clamp anyway: never fault on bad input.
-            int64_t o = off[m / T] + t, o1 = o + 1;
+            int64_t o = off[bq] + t, o1 = o + 1;
             if (o < 0) o = 0; if (o >= bs.n_corpus) o = bs.n_corpus - 1;
             if (o1 < 0) o1 = 0; if (o1 >= bs.n_corpus) o1 = bs.n_corpus - 1;
             v = bs.corpus[o];
-            if (c == 0) { bs.x_ids[m] = v; bs.y_ids[m] = bs.corpus[o1]; }
+            if (lane == 0) { bs.x_ids[m] = v; bs.y_ids[m] = bs.corpus[o1]; }
         } else {
             v = idx[m];
         }
         v = v < 0 ? 0 : (v >= V ? V - 1 : v);
+      for (int j = lane; j < cv; j += 64) {
+        const int c = j * VEC;
         if (onehot) {
             // row m of the one-hot matrix, 8 columns per (m, c) work item: the dY^T X operand that turns the token-table
             // gradient into one more problem of the grouped dW GEMM (no atomics, no scatter)
-            const int j = (int)(i % cv);
             if (VEC == 4 && j * 8 < ld_onehot) {
                 bf16x8 o;
 #pragma unroll
@@ -102,6 +108,7 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ idx, const float* _
             if (pos) a += pos[(int64_t)t * C + c];
             x[m * C + c] = a;
         }
+      }
     }
 }
 
